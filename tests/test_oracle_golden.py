@@ -1,0 +1,227 @@
+"""Pin the CPU oracle (oracle/parc_oracle.c) against golden vectors produced by the REAL reference
+(tests/golden/make_golden.py).  CPU-only; tolerance 2e-6 unless a case states otherwise."""
+import numpy as np
+import pytest
+
+from conftest import golden
+
+TOL = 2e-6
+
+
+def close(a, b, tol=TOL, what=""):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    both_nan = np.isnan(a) & np.isnan(b)
+    err = np.abs(a - b) / np.maximum(1.0, np.abs(b))
+    err[both_nan] = 0.0
+    assert np.nanmax(err) <= tol and not np.any(np.isnan(err)), f"{what}: max err {np.nanmax(err)} at {np.nanargmax(err)}"
+
+
+def test_quat_ops(oracle):
+    g = golden("quat_ops")
+    a, b, v, t, e, axis, angle = (g[k] for k in ["a", "b", "v", "t", "e", "axis", "angle"])
+    close(oracle.quat_mul(a, b), g["quat_mul"], what="quat_mul")
+    close(oracle.quat_multiply(a, b), g["quat_multiply"], what="quat_multiply")
+    close(oracle.quat_rotate(a, v), g["quat_rotate"], what="quat_rotate")
+    close(oracle.quat_conjugate(a), g["quat_conjugate"])
+    close(oracle.quat_pos(a), g["quat_pos"])
+    close(oracle.normalize(v), g["normalize"])
+    ax, an = oracle.quat_to_axis_angle(a)
+    close(ax, g["q2aa_axis"], what="q2aa axis"); close(an, g["q2aa_angle"], what="q2aa angle")
+    close(oracle.axis_angle_to_quat(axis, angle), g["aa2q"], what="aa2q")
+    eax, ean = oracle.exp_map_to_axis_angle(e)
+    close(eax, g["e2aa_axis"], what="e2aa axis"); close(ean, g["e2aa_angle"], what="e2aa angle")
+    close(oracle.exp_map_to_quat(e), g["exp_map_to_quat"], what="exp_map_to_quat")
+    close(oracle.quat_to_exp_map(a), g["quat_to_exp_map"], what="quat_to_exp_map")
+    close(oracle.quat_diff(a, b), g["quat_diff"])
+    # near-opposite/identical pairs amplify 1-ulp differences of the product through atan2 near 0/pi
+    close(oracle.quat_diff_angle(a, b), g["quat_diff_angle"], tol=2e-4, what="quat_diff_angle")
+    close(oracle.quat_normalize(a * np.float32(1.7)), g["quat_normalize"])
+    close(oracle.quat_to_tan_norm(a), g["quat_to_tan_norm"])
+    close(oracle.slerp(a, b, t), g["slerp"], tol=5e-6, what="slerp")
+    close(oracle.calc_heading(a), g["calc_heading"], tol=5e-6)
+    close(oracle.calc_heading_quat_inv(a), g["calc_heading_quat_inv"])
+    close(oracle.rotate_2d_vec(v[:, :2], angle), g["rotate_2d_vec"])
+    close(oracle.normalize_angle(angle * np.float32(3.0)), g["normalize_angle"], tol=5e-6)
+
+
+def test_kin_ops(oracle, orc_char):
+    g = golden("kin_ops")
+    close(oracle.dof_to_rot(orc_char, g["dof"]), g["joint_rot"], what="dof_to_rot")
+    close(oracle.rot_to_dof(orc_char, g["joint_rot"]), g["dof_back"], tol=5e-6, what="rot_to_dof")
+    close(oracle.rot_to_dof(orc_char, g["joint_rot_rand"]), g["dof_rand"], tol=5e-6, what="rot_to_dof rand")
+    bp, br = oracle.forward_kinematics(orc_char, g["root_pos"], g["root_rot"], g["joint_rot"])
+    close(bp, g["body_pos"], what="fk pos"); close(br, g["body_rot"], what="fk rot")
+    bp, br = oracle.forward_kinematics(orc_char, g["root_pos"], g["root_rot"], g["joint_rot_rand"])
+    close(bp, g["body_pos_rand"]); close(br, g["body_rot_rand"])
+    close(oracle.compute_dof_vel(orc_char, g["joint_rot"], g["joint_rot1"], 1.0 / 30.0), g["dof_vel"], tol=2e-5, what="dof_vel")
+
+
+def test_known_answers_survey(oracle, orc_char):
+    """SURVEY.md §8(c) known-answer samples on sfu.pkl (measured on the reference during the survey)."""
+    from helpers import load_clips, make_orc_mlib
+    clips = load_clips(["sfu"])
+    lib = make_orc_mlib(oracle, orc_char, clips, [1.0])
+    i0, i1, bl = oracle.mlib_calc_frame_blend(lib, [0, 0], [0.10, 0.21])
+    assert (i0[0], i1[0]) == (3, 4) and abs(bl[0]) < 1e-6
+    assert (i0[1], i1[1]) == (6, 7) and abs(bl[1] - 0.2999997) < 1e-6
+    o = oracle.mlib_calc_motion_frame(lib, [0, 0], [0.10, 0.21])
+    close(o["root_pos"][0], [10.8036976, 1.8566505, 0.7566922], tol=1e-6)
+    close(o["root_pos"][1], [10.8226118, 2.3026748, 0.7736420], tol=1e-6)
+    close(o["root_rot"][1], [-0.0113259, -0.0050410, 0.6899159, 0.7237490], tol=1e-6)
+    bp, _ = oracle.forward_kinematics(orc_char, o["root_pos"], o["root_rot"], o["joint_rot"])
+    close(bp[0, 11], [10.9086103, 1.8863832, 0.1450104], tol=1e-6)
+    close(bp[0, 8], [10.5566044, 2.0967307, 0.7700925], tol=1e-6)
+    close(bp[1, 11], [10.9210749, 2.3483460, 0.0427647], tol=1e-6)
+    close(bp[1, 8], [10.5470676, 2.4380567, 0.7927424], tol=1e-6)
+    dof = oracle.rot_to_dof(orc_char, o["joint_rot"])
+    close(dof[1, 0:6], [-0.0387498, 0.4994673, -0.0135002, 0.0099086, 0.1129964, 0.0633409], tol=1e-6)
+    close(o["dof_vel"][1, 0:4], [-1.5708344, 0.0133573, 1.3118259, 0.2720484], tol=2e-6)
+    ray = oracle.ray_points_cone(0.05, 2, 60, 3, 3, 0.26179938779)
+    close(ray[0], [-0.0707107, 0.0707107], tol=1e-6); close(ray[62], [2.1213202, -2.1213202], tol=1e-6)
+    close(ray[3 * 63 + 62], [3.0, 0.0], tol=1e-6); close(ray[6 * 63 + 62], [2.1213202, 2.1213202], tol=1e-6)
+
+
+def test_motion_lib(oracle, orc_char):
+    from helpers import CLIPS4, load_clips, make_orc_mlib
+    g = golden("motion_lib")
+    clips = load_clips(CLIPS4)
+    lib = make_orc_mlib(oracle, orc_char, clips, [1.0, 1.5, 2.0, 2.5])
+    F = int(g["frame_root_pos"].shape[0]); M = 4
+    A = oracle.mlib_array
+    close(A(lib, "motion_weights", (M,)), g["motion_weights"])
+    close(A(lib, "motion_lengths", (M,)), g["motion_lengths"], tol=0)
+    close(A(lib, "motion_dt", (M,)), g["motion_dt"], tol=0)
+    assert np.array_equal(A(lib, "motion_start_idx", (M,), np.int64), g["motion_start_idx"])
+    close(A(lib, "motion_root_pos_delta", (M, 3)), g["motion_root_pos_delta"], tol=0)
+    close(A(lib, "frame_root_vel", (F, 3)), g["frame_root_vel"], tol=0, what="root_vel")
+    close(A(lib, "frame_root_ang_vel", (F, 3)), g["frame_root_ang_vel"], tol=3e-5, what="root_ang_vel")
+    close(A(lib, "frame_dof_vel", (F, 28)), g["frame_dof_vel"], tol=3e-5, what="dof_vel")
+    i0, i1, bl = oracle.mlib_calc_frame_blend(lib, g["q_ids"], g["q_times"])
+    assert np.array_equal(i0, g["idx0"]) and np.array_equal(i1, g["idx1"])
+    close(bl, g["blend"], tol=0, what="blend")
+    o = oracle.mlib_calc_motion_frame(lib, g["q_ids"], g["q_times"])
+    for k in ["root_pos", "root_rot", "joint_rot", "contacts"]:
+        close(o[k], g[k], tol=5e-6, what=k)
+    for k in ["root_vel", "root_ang_vel", "dof_vel"]:
+        close(o[k], g[k], tol=3e-5, what=k)
+    bp, _ = oracle.forward_kinematics(orc_char, o["root_pos"], o["root_rot"], o["joint_rot"])
+    close(bp, g["body_pos"], tol=5e-6)
+    close(oracle.rot_to_dof(orc_char, o["joint_rot"]), g["dof_pos"], tol=1e-5)
+
+
+def test_motion_lib_wrap(oracle, orc_char):
+    from helpers import load_clips, make_orc_mlib
+    g = golden("motion_lib_wrap")
+    clips = load_clips(["civilization"])
+    clips[0]["loop_mode"] = 1
+    lib = make_orc_mlib(oracle, orc_char, clips, [1.0])
+    o = oracle.mlib_calc_motion_frame(lib, np.zeros(64, np.int64), g["q_times"])
+    for k in ["root_pos", "root_rot", "joint_rot", "contacts"]:
+        close(o[k], g[k], tol=5e-6, what=k)
+
+
+def test_terrain_lookup(oracle):
+    g = golden("terrain_lookup")
+    close(oracle.ray_points_cone(0.05, 2, 60, 3, 3, 0.26179938779), g["ray_points"], tol=1e-6, what="ray fan")
+    t = oracle.make_terrain(g["hf"], g["min_point"], g["dxdy"])
+    assert np.array_equal(oracle.terrain_grid_index(t, g["points"]), g["grid_index"])
+    assert np.array_equal(oracle.terrain_hf_vals(t, g["points"]), g["hf_vals"])
+
+
+def test_done_and_contact_reward(oracle):
+    from helpers import default_cfg
+    g = golden("done_table")
+    cfg = default_cfg(oracle, 128)
+    d = oracle.compute_done(cfg, 15, g["time"], g["root_rot"], g["body_pos"], g["tar_root_rot"], g["tar_body_pos"])
+    assert np.array_equal(d, g["done"])
+    assert set(np.unique(d)) >= {0, 1}
+    close(oracle.contact_reward(g["tar_contacts"], g["contact_forces"], np.full(15, 5.0, np.float32)), g["contact_r"])
+
+
+def test_env_step_pipeline(oracle, orc_char):
+    """The reference's own IGEnv._post_physics_step on injected state, 3 consecutive control steps."""
+    from helpers import build_oracle_scene, load_state_into
+    g = golden("env_step")
+    scene = build_oracle_scene(oracle, orc_char, g)
+    st = scene["state"]
+    for s in range(3):
+        load_state_into(st, g, f"s{s}_in_")
+        oracle.env_post_physics_step(orc_char, scene["lib"], scene["terrain"], scene["cfg"], st)
+        oracle.env_update_curriculum(scene["lib"], scene["cfg"], st)
+        p = f"s{s}_out_"
+        assert np.array_equal(st["timestep_buf"], g[p + "timestep"])
+        close(st["time_buf"], g[p + "time"], tol=0, what="time")
+        for k in ["ref_root_pos", "ref_root_rot", "ref_joint_rot", "ref_body_pos", "ref_contacts", "ref_dof_pos"]:
+            close(st[k], g[p + k], tol=1e-5, what=k)
+        for k in ["ref_root_vel", "ref_root_ang_vel", "ref_dof_vel"]:
+            close(st[k], g[p + k], tol=3e-5, what=k)
+        # rays: identical except where a 1-ulp sin/cos difference moves a point across a cell edge
+        ray_bad = np.abs(st["ray_hfs"] - g[p + "ray_hfs"]) > 1e-5
+        assert ray_bad.mean() < 2e-4, ray_bad.sum()
+        obs_err = np.abs(st["obs"] - g[p + "obs"])
+        obs_err[:, 871:][ray_bad] = 0
+        assert obs_err.max() <= 1e-5, (obs_err.max(), np.unravel_index(obs_err.argmax(), obs_err.shape))
+        close(st["reward"], g[p + "reward"], tol=1e-5, what="reward")
+        names = ["pose_r", "vel_r", "root_pos_r", "root_vel_r", "key_pos_r", "contact_penalty", "total_r"]
+        for i, nm in enumerate(names):
+            close(st["reward_terms"][i], g[p + "r_" + nm], tol=1e-5, what=nm)
+        close(st["tracking_error"], g[p + "tracking_error"], tol=1e-5, what="tracking_error")
+        assert np.array_equal(st["done"], g[p + "done"])
+        close(st["fail_rates"], g[p + "fail_rates"], tol=0, what="fail_rates")
+
+
+def test_env_reset(oracle, orc_char):
+    from helpers import build_oracle_scene
+    g = golden("env_step")
+    scene = build_oracle_scene(oracle, orc_char, g)
+    st = scene["state"]
+    n = scene["cfg"].num_envs
+    ids = np.arange(n)
+    oracle.env_reset_with(orc_char, scene["lib"], scene["terrain"], scene["cfg"], st, ids, g["reset_motion_ids"],
+                          g["reset_terrain_ids"], g["reset_time_offsets"], g["reset_xy_noise"])
+    for k in ["char_root_rot", "char_root_vel", "char_root_ang_vel", "char_dof_pos", "char_dof_vel"]:
+        close(st[k], g["reset_" + k], tol=3e-5, what=k)
+    close(st["char_root_pos"], g["reset_char_root_pos"], tol=1e-5)
+    close(st["ref_root_pos"], g["reset_ref_root_pos"], tol=1e-5)
+    close(st["ref_contacts"], g["reset_ref_contacts"], tol=1e-5)
+    oracle.env_refresh_rays(scene["terrain"], scene["cfg"], st)
+    oracle.env_compute_obs(orc_char, scene["lib"], scene["cfg"], st, ids)
+    ray_bad = np.abs(st["ray_hfs"] - g["reset_ray_hfs"]) > 1e-5
+    assert ray_bad.mean() < 2e-4
+    err = np.abs(st["obs"] - g["reset_obs"]); err[:, 871:][ray_bad] = 0
+    assert err.max() <= 1e-5, err.max()
+
+
+def test_recorded_isaacgym_obs(oracle, orc_char):
+    """an obs stream recorded from a real Isaac Gym run ships in
+    dec2024_teaser_717_1_opt_dm.pkl.  Root tan-norm, 10 of 14 joint tan-norms (the 4 arm joints used an
+    older XML convention), contact flags and all in-bounds height rays must reproduce from the file's frames."""
+    from helpers import load_clips
+    g = golden("recorded_obs_dec2024_teaser_717_1_opt_dm")
+    obs = g["obs"]
+    clip = load_clips(["dec2024_teaser_717_1_opt_dm"])[0]
+    n = obs.shape[0]
+    assert obs.shape == (142, 1312) and clip["root_pos"].shape[0] == n
+    hinv = oracle.calc_heading_quat_inv(clip["root_rot"])
+    local = oracle.quat_mul(hinv, clip["root_rot"])
+    close(oracle.quat_to_tan_norm(local), obs[:, 0:6], tol=5e-6, what="root tan-norm")
+    jt = oracle.quat_to_tan_norm(clip["joint_rot"].reshape(-1, 4)).reshape(n, 14, 6)
+    rec = obs[:, 12:96].reshape(n, 14, 6)
+    good = [j for j in range(14) if j not in (2, 3, 5, 6)]  # arm joints: older convention in the recording
+    close(jt[:, good], rec[:, good], tol=5e-6, what="joint tan-norm")
+    assert np.array_equal(obs[:, 856:871], clip["contacts"])
+    # height rays on the clip's own terrain slice: exact on every ray whose sample lies inside the slice
+    t = oracle.make_terrain(clip["hf"], clip["min_point"], [clip["dx"], clip["dx"]])
+    ray = golden("terrain_lookup")["ray_points"]
+    heading = oracle.calc_heading(clip["root_rot"])
+    X, Y = clip["hf"].shape
+    tot = 0; ok = 0
+    for i in range(n):
+        p = oracle.rotate_2d_vec(ray, np.full(441, heading[i], np.float32)) + clip["root_pos"][i, 0:2]
+        idx_f = (p - clip["min_point"]) / np.float32(clip["dx"])
+        inb = (idx_f[:, 0] > 0.01) & (idx_f[:, 0] < X - 1.01) & (idx_f[:, 1] > 0.01) & (idx_f[:, 1] < Y - 1.01)
+        h = np.clip(oracle.terrain_hf_vals(t, p) - clip["root_pos"][i, 2], -3.0, 3.0)
+        d = np.abs(h - obs[i, 871:])[inb]
+        tot += inb.sum(); ok += (d < 1e-5).sum()
+    assert tot > 0.7 * n * 441 and ok / tot > 0.999, (tot, ok)
