@@ -1,0 +1,228 @@
+/*
+ * parc_env.h — C-ABI of libparc_env.so: the MI355X (gfx950) motion-tracking environment.
+ *
+ * This is the drop-in boundary for the reference's per-env step.  The reference has no FFI: the
+ * hot path sits behind the Python class contract BaseEnv (PARC/motion_tracker/envs/base_env.py:20-72)
+ * as driven by BaseAgent (PARC/motion_tracker/learning/base_agent.py:291-370).  A thin Python shim
+ * (parc_amd/envs/hip_parkour_env.py, ctypes) implements that class contract on top of the entry points
+ * below; each entry point cites the reference code it replaces (file:line relative to /root/reference).
+ *
+ * Conventions
+ *   - plain C, no torch types: pointers + sizes.  "_host" pointers are copied during the call and may
+ *     be freed afterwards; "_dev" pointers are device memory OWNED BY THE CALLER (PyTorch tensors) that
+ *     must stay alive while bound; the library never frees them.
+ *   - every launch goes to the hipStream_t passed in (void* here so that the header needs no HIP
+ *     include); nothing in step/reset synchronises with the host.
+ *   - return 0 on success, negative ParcStatus on error; parc_last_error() gives a thread-local text.
+ *   - single caller thread per handle; handles are independent (one process per GPU needs no locks).
+ *   - quaternions are (x, y, z, w); all floating point is fp32; row-major [N][...] arrays.
+ */
+#ifndef PARC_ENV_H
+#define PARC_ENV_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PARC_ABI_VERSION 1
+#define PARC_MAX_BODIES 16   /* 15 quats + root position share one 16-lane group */
+#define PARC_MAX_DOFS 40     /* dof velocities live in floats [88,128) of a 128-float frame record */
+#define PARC_MAX_TAR_STEPS 6 /* 2 + steps skeletons <= 8 lane groups of 8 */
+#define PARC_MAX_KEY_BODIES 8
+#define PARC_MAX_FK_PATHS 8
+#define PARC_MAX_FK_DEPTH 8
+#define PARC_MAX_GEOMS 24
+
+typedef enum {
+    PARC_OK = 0,
+    PARC_ERR_INVALID = -1,     /* bad argument / unsupported configuration */
+    PARC_ERR_HIP = -2,         /* a HIP runtime call failed */
+    PARC_ERR_STATE = -3,       /* call order (e.g. step before bind/load) */
+    PARC_ERR_NO_DEVICE = -4    /* no gfx950 device visible */
+} ParcStatus;
+
+typedef enum { PARC_JOINT_ROOT = 0, PARC_JOINT_HINGE = 1, PARC_JOINT_SPHERICAL = 2, PARC_JOINT_FIXED = 3 } ParcJointType;
+typedef enum { PARC_DONE_NULL = 0, PARC_DONE_FAIL = 1, PARC_DONE_SUCC = 2, PARC_DONE_TIME = 3 } ParcDoneFlag; /* base_env.py:14-18 */
+typedef enum { PARC_LOOP_CLAMP = 0, PARC_LOOP_WRAP = 1 } ParcLoopMode;                                        /* motion_lib.py:14-16 */
+typedef enum { PARC_GEOM_BOX = 0, PARC_GEOM_SPHERE = 1, PARC_GEOM_CAPSULE = 2 } ParcGeomType;
+
+typedef struct ParcEnv ParcEnv;
+
+/* Character tables — what KinCharModel.load_char_file / init produce (kin_char_model.py:154-190,235). */
+typedef struct {
+    int32_t num_bodies;                                  /* B, body 0 = root */
+    int32_t dof_size;                                    /* D */
+    int32_t parent[PARC_MAX_BODIES];
+    float local_translation[PARC_MAX_BODIES][3];
+    float local_rotation[PARC_MAX_BODIES][4];
+    int32_t joint_type[PARC_MAX_BODIES];                 /* ParcJointType */
+    float joint_axis[PARC_MAX_BODIES][3];
+    int32_t dof_idx[PARC_MAX_BODIES];
+    int32_t fk_paths[PARC_MAX_FK_PATHS][PARC_MAX_FK_DEPTH]; /* root-to-leaf body chains, -1 padded */
+} ParcCharModel;
+
+/* Rigid-body / actuator parameters the reference hands to Isaac Gym through the MJCF
+ * (ig_char_env.py:100-143, humanoid.xml) and the sim block of dm_env_default.yaml:175-186. */
+typedef struct {
+    int32_t num_geoms;
+    int32_t geom_body[PARC_MAX_GEOMS];
+    int32_t geom_type[PARC_MAX_GEOMS];
+    float geom_pos[PARC_MAX_GEOMS][3];   /* sphere/box centre, capsule end 0 (body frame) */
+    float geom_pos2[PARC_MAX_GEOMS][3];  /* capsule end 1 */
+    float geom_size[PARC_MAX_GEOMS][3];  /* sphere r | box half extents | capsule r */
+    float geom_density[PARC_MAX_GEOMS];
+    float dof_stiffness[PARC_MAX_DOFS];  /* PD kp (MJCF joint stiffness) */
+    float dof_damping[PARC_MAX_DOFS];    /* PD kd */
+    float dof_armature[PARC_MAX_DOFS];
+    float dof_effort[PARC_MAX_DOFS];     /* motor gear = max torque */
+    float dof_lower[PARC_MAX_DOFS];
+    float dof_upper[PARC_MAX_DOFS];
+    float gravity_z;                     /* ig_env.py:142-145 */
+    float sim_dt;                        /* 1 / sim_freq */
+    int32_t sim_steps;                   /* sim_freq / control_freq (ig_env.py:113) */
+    int32_t substeps;                    /* dm_env_default.yaml:186 */
+    int32_t solver_iterations;           /* num_position_iterations */
+    float friction;                      /* ig_util.py:10 */
+    float restitution;
+    float contact_offset;
+    float max_depenetration_velocity;
+    float angular_damping;               /* ig_char_env.py:142 */
+    float max_angular_velocity;          /* ig_char_env.py:143 */
+} ParcDynamicsParams;
+
+/* Environment constants — the keys IGParkourEnv.__init__ reads (ig_parkour_env.py:43-149). */
+typedef struct {
+    uint32_t abi_version;       /* PARC_ABI_VERSION */
+    uint32_t struct_size;       /* sizeof(ParcEnvConfig) */
+    int32_t device;             /* HIP device ordinal */
+    int32_t num_envs;           /* N local envs of this handle */
+    ParcCharModel model;
+    int32_t num_key_bodies;
+    int32_t key_body_ids[PARC_MAX_KEY_BODIES];
+    int32_t num_tar_obs_steps;
+    int32_t tar_obs_steps[PARC_MAX_TAR_STEPS];
+    int32_t num_rays;
+    const float *ray_points_host;            /* [R][2] geom_util.get_xy_points_cone:251 */
+    double control_dt;                       /* 1 / control_freq (python double, cast like torch does) */
+    float episode_length;
+    float min_obs_h, max_obs_h;
+    float pose_w, vel_w, root_pos_w, root_vel_w, key_pos_w;   /* already divided by their sum (:91-101) */
+    float joint_err_w[PARC_MAX_BODIES];      /* [J] */
+    float dof_err_w[PARC_MAX_DOFS];          /* [D] */
+    float contact_weights[PARC_MAX_BODIES];  /* [B] */
+    float pose_termination_dist[PARC_MAX_BODIES]; /* [J] */
+    float root_pos_termination_dist, root_rot_termination_angle;
+    int32_t enable_early_termination, pose_termination, track_root, track_root_h;
+    int32_t report_tracking_error;
+    float fail_rate_ema_weight;              /* dm_env.py:88 */
+    float min_motion_weight;                 /* dm_env.py:26 */
+    float rand_root_pos_offset_scale;        /* mgdm_dm_util.py:102-106 */
+    int32_t rand_reset;                      /* dm_env.py:500-504 */
+    int32_t demo_mode;                       /* dm_env.py:479-480 */
+    const float *env_offsets_host;           /* [N][3] ig_parkour_env.py:389-398 (global env ids of this shard) */
+    float action_low[PARC_MAX_DOFS], action_high[PARC_MAX_DOFS]; /* ig_char_env.py:307-347 */
+    int32_t body_pos_from_fk;                /* 1: rigid-body positions := FK(char state) inside the step
+                                                (reduced-coordinate sim / kinematic mode); 0: read bound buffer */
+    int32_t enable_dynamics;                 /* 0 = kinematic-only step (state injected by the caller) */
+    ParcDynamicsParams dynamics;             /* used when enable_dynamics */
+    uint64_t seed;
+} ParcEnvConfig;
+
+/* Motion clips as MotionLib._load_motion_file receives them (motion_lib.py:255-401); the library
+ * derives root_vel / root_ang_vel / dof_vel on the device and packs 512-byte frame records. */
+typedef struct {
+    int32_t num_motions;
+    const int32_t *num_frames_host;   /* [M] */
+    const int32_t *fps_host;          /* [M] */
+    const int32_t *loop_modes_host;   /* [M] ParcLoopMode */
+    const double *weights_host;       /* [M] un-normalised */
+    const float *root_pos_host;       /* [F][3], clips concatenated */
+    const float *root_rot_host;       /* [F][4] */
+    const float *joint_rot_host;      /* [F][J][4] */
+    const float *contacts_host;       /* [F][B] or NULL (=> zeros, motion_lib.py:345-347) */
+} ParcMotionClips;
+
+/* Device buffers owned by the caller.  NULL = that optional output is not written. */
+typedef struct {
+    /* simulator-side character state (ig_char_env.py:173-196): read by step, written by reset/dynamics */
+    float *char_root_pos, *char_root_rot, *char_root_vel, *char_root_ang_vel; /* [N][3|4|3|3] */
+    float *char_dof_pos, *char_dof_vel;                                       /* [N][D] */
+    float *char_body_pos;                                                     /* [N][B][3] */
+    float *contact_forces;                                                    /* [N][B][3] */
+    /* bookkeeping (dm_env.py:76-78, ig_parkour_env.py:616-621) */
+    int32_t *motion_ids, *terrain_ids;                                        /* [N] */
+    float *time_offsets;                                                      /* [N] */
+    int32_t *timestep;                                                        /* [N] */
+    float *time;                                                              /* [N] optional */
+    int64_t *ep_num;                                                          /* [N] optional */
+    /* outputs of the step (BaseEnv.step contract) */
+    float *obs;                                                               /* [N][obs_dim] */
+    float *reward;                                                            /* [N] */
+    int32_t *done;                                                            /* [N] ParcDoneFlag */
+    float *reward_terms;                                                      /* [7][N] pose,vel,root_pos,root_vel,key_pos,contact,total */
+    float *tracking_error;                                                    /* [N][7] optional */
+    /* optional mirrors of the reference's ref_* tensors (ig_parkour_env.py:560-571) */
+    float *ref_root_pos, *ref_root_rot, *ref_root_vel, *ref_root_ang_vel;
+    float *ref_joint_rot, *ref_dof_pos, *ref_dof_vel, *ref_body_pos, *ref_contacts;
+    float *ray_hfs;                                                           /* [N][R] optional */
+} ParcEnvBuffers;
+
+const char *parc_last_error(void);
+int parc_abi_version(void);
+
+/* IGParkourEnv.__init__ (ig_parkour_env.py:43-149) minus Isaac Gym */
+int parc_env_create(const ParcEnvConfig *cfg, ParcEnv **out);
+void parc_env_destroy(ParcEnv *env);
+/* obs width for this configuration (IGEnv.get_obs_space, ig_env.py:86-96) */
+int parc_env_obs_dim(const ParcEnv *env);
+
+/* MotionLib._load_motion_file (motion_lib.py:255-401) */
+int parc_env_load_motions(ParcEnv *env, const ParcMotionClips *clips);
+/* DeepMimicEnv.build_terrain_square / load_terrain result (dm_env.py:157-316,447-463):
+ * hf [X][Y] x-major, motion_offsets [M][T][2] */
+int parc_env_load_terrain(ParcEnv *env, const float *hf_host, int32_t X, int32_t Y, float min_x, float min_y,
+                          float dx, float dy, const float *motion_offsets_host, int32_t M, int32_t T);
+/* IGCharEnv._build_sim_tensors / IGParkourEnv._build_data_buffers tensor views */
+int parc_env_bind_buffers(ParcEnv *env, const ParcEnvBuffers *bufs);
+
+/* IGEnv.step (ig_env.py:66-84): clip action -> [dynamics] -> _post_physics_step.  action_dev [N][D]
+ * may be NULL when enable_dynamics == 0. */
+int parc_env_step(ParcEnv *env, const float *action_dev, void *stream);
+/* IGParkourEnv.reset (ig_parkour_env.py:809-829) with device RNG.  env_ids_dev int64 [k]; k < 0 = all. */
+int parc_env_reset(ParcEnv *env, const int64_t *env_ids_dev, int32_t k, void *stream);
+/* Same with the random draws injected (parity tests): all arrays device, length k. */
+int parc_env_reset_with(ParcEnv *env, const int64_t *env_ids_dev, int32_t k, const int32_t *motion_ids_dev,
+                        const int32_t *terrain_ids_dev, const float *t0_dev, const float *xy_noise_dev, void *stream);
+/* _update_observations(env_ids) (ig_env.py:396-403): rays + obs rows only. k < 0 = all. */
+int parc_env_compute_obs(ParcEnv *env, const int64_t *env_ids_dev, int32_t k, void *stream);
+
+/* dm_env.py:84-88 curriculum state */
+int parc_env_get_fail_rates(ParcEnv *env, float *out_host, int32_t M);
+int parc_env_set_fail_rates(ParcEnv *env, const float *in_host, int32_t M);
+/* per-motion tables derived at load (motion_lib.py:361-384); any pointer may be NULL */
+int parc_env_get_motion_info(ParcEnv *env, float *lengths_host, float *weights_host, int32_t M);
+int parc_env_set_rand_reset(ParcEnv *env, int32_t rand_reset, int32_t demo_mode, float root_pos_offset_scale);
+int parc_env_set_start_time_fraction(ParcEnv *env, const float *frac_dev /* [N] or NULL */);
+
+/* Stand-alone operators on device arrays (cfg-1 plumbing and the KinCharModel / MotionLib mirrors):
+ * kin_char_model.py:586,601,617; motion_lib.py:94 */
+int parc_dof_to_rot(ParcEnv *env, const float *dof_dev, float *joint_rot_dev, int32_t n, void *stream);
+int parc_rot_to_dof(ParcEnv *env, const float *joint_rot_dev, float *dof_dev, int32_t n, void *stream);
+int parc_forward_kinematics(ParcEnv *env, const float *root_pos_dev, const float *root_rot_dev,
+                            const float *joint_rot_dev, float *body_pos_dev, float *body_rot_dev, int32_t n, void *stream);
+int parc_calc_motion_frame(ParcEnv *env, const int32_t *motion_ids_dev, const float *times_dev, int32_t n,
+                           float *root_pos_dev, float *root_rot_dev, float *root_vel_dev, float *root_ang_vel_dev,
+                           float *joint_rot_dev, float *dof_vel_dev, float *contacts_dev, void *stream);
+/* copy the derived frame tables back (tests): [F][3],[F][3],[F][D] */
+int parc_env_get_frame_vel_tables(ParcEnv *env, float *root_vel_host, float *root_ang_vel_host, float *dof_vel_host);
+
+/* Timing of the dominant kernel with hipEvents on the launch stream (bench.py roofline leg). */
+int parc_env_profile_step(ParcEnv *env, const float *action_dev, void *stream, int32_t iters, float *avg_ms_out,
+                          float *avg_post_kernel_ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PARC_ENV_H */

@@ -1,0 +1,1316 @@
+// parc_env.hip — gfx950 kernels + the C-ABI of include/parc_env.h.
+//
+// One wavefront (64 lanes) owns one environment per iteration of a grid-stride loop:
+//   * the joint hierarchy / per-body tables are staged once per wave into LDS;
+//   * the 8 skeletons of a step (character, reference, 6 look-ahead targets) are 8 rows of 16 lanes:
+//     lane (row, i) produces quaternion i of that row (slerp of two 512-byte frame records, or
+//     dof->quat for the character) and its tan-norm observation in the same instruction stream;
+//   * FK runs one root-to-leaf chain per lane (8 rows x 8 chains), no cross-lane traffic;
+//   * the 441 height rays read a (2r+1)^2 terrain tile staged in LDS;
+//   * the 1312-float observation row is assembled in LDS and streamed out as 16-byte stores.
+// No MFMA: the work is quaternion algebra and gathers.  HBM traffic per env-step is the state read
+// (456 B + 24 B bookkeeping) and the observation/reward write (5.3 KB); motion records and the terrain
+// grid stay cache resident.
+//
+// Reference semantics: file:line citations relative to /root/reference.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/parc_env.h"
+#include "parc_math.hpp"
+
+using namespace parc;
+
+// ------------------------------------------------------------------------------------------------
+// device-side tables
+// ------------------------------------------------------------------------------------------------
+#define REC_F4 32            // one frame record = 32 float4 = 512 B
+#define REC_Q_POS 15         // float4 #15 = root position
+#define REC_Q_CONTACT 16     // float4 #16..19 = contacts
+#define REC_Q_VEL 20         // float4 #20 = root_vel, #21 = root_ang_vel, #22.. = dof_vel
+
+struct DevTables { // per-lane indexed tables, staged into LDS once per wave
+    int parent[16];
+    int jtype[16];
+    int dof_idx[16];
+    float axis[16][4];
+    float lt[16][4];
+    float lr[16][4];
+    int fk_paths[PARC_MAX_FK_PATHS][PARC_MAX_FK_DEPTH];
+    float tstep[8];          // control_dt * tar_obs_steps (fp32 product, mgdm_dm_util.py:232)
+    int key_ids[8];
+    float joint_err_w[16];
+    float dof_err_w[PARC_MAX_DOFS];
+    float contact_w[16];
+    float pose_term_dist[16];
+};
+
+struct MotionMeta { // 32 B
+    int start, nframes;
+    float length;
+    int loop;
+    float dx, dy, dz;
+    float fps;
+};
+
+struct StepParams {
+    int N, B, J, D, K, S, R, M, T;
+    int obs_dim, off_dofvel, off_key, off_tar, tar_w, off_tarc, off_cc, off_hf;
+    float dt_f, episode_length, min_obs_h, max_obs_h;
+    float pose_w, vel_w, root_pos_w, root_vel_w, key_pos_w;
+    float root_pos_term_sq, root_rot_term;
+    int early_term, pose_term, track_root, track_root_h, tracking, body_pos_from_fk;
+    // terrain
+    const float *hf; int X, Y; float min_x, min_y, dx, dy; int tile_r;
+    // tables
+    const float4 *records; const MotionMeta *meta; const float *motion_offsets; const float *env_offsets;
+    const float *ray_points; const DevTables *tables;
+    // curriculum hand-off
+    unsigned char *ema_code; int *done_list; int *done_count;
+    ParcEnvBuffers buf;
+};
+
+struct Blend { int i0, i1; float b; };
+
+// motion_lib.py:425-438 (+ calc_phase :520)
+__device__ __forceinline__ Blend frame_blend(const MotionMeta &m, float t) {
+    float phase = t / m.length;
+    if (m.loop == PARC_LOOP_WRAP) phase = phase - floorf(phase);
+    phase = fminf(fmaxf(phase, 0.f), 1.f);
+    float pf = phase * (float)(m.nframes - 1);
+    int f0 = (int)pf;                       // .long(): truncation
+    f0 = max(0, min(f0, m.nframes - 1));    // memory safety only (no-op for finite phase)
+    int f1 = min(f0 + 1, m.nframes - 1);
+    Blend r;
+    r.b = pf - (float)f0;
+    r.i0 = f0 + m.start;
+    r.i1 = f1 + m.start;
+    return r;
+}
+
+// Joint.dof_to_rot kin_char_model.py:61-81
+__device__ __forceinline__ Q4 joint_dof_to_rot(int type, const float *axis4, const float *dof) {
+    if (type == PARC_JOINT_HINGE) return axis_angle_to_quat(mk3(axis4[0], axis4[1], axis4[2]), dof[0]);
+    if (type == PARC_JOINT_SPHERICAL) return exp_map_to_quat(mk3(dof[0], dof[1], dof[2]));
+    return mk4(0.f, 0.f, 0.f, 1.f);
+}
+
+// Joint.rot_to_dof kin_char_model.py:83-105
+__device__ __forceinline__ void joint_rot_to_dof(int type, const float *axis4, Q4 q, float *out) {
+    if (type == PARC_JOINT_HINGE) {
+        V3 axis; float angle;
+        quat_to_axis_angle(q, axis, angle);
+        float dot = axis4[0] * axis.x + axis4[1] * axis.y + axis4[2] * axis.z;
+        if (dot < 0.f) angle = angle * -1.f;
+        out[0] = angle;
+    } else if (type == PARC_JOINT_SPHERICAL) {
+        V3 e = quat_to_exp_map(q);
+        out[0] = e.x; out[1] = e.y; out[2] = e.z;
+    }
+}
+
+// terrain_util.py:146-152 — unclamped nearest cell (round half to even)
+__device__ __forceinline__ int cell_index(float p, float mn, float d) {
+    float f = rintf((p - mn) / d);
+    f = fminf(fmaxf(f, -1.0e9f), 1.0e9f);
+    return (int)f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// the step kernel: IGEnv._post_physics_step (ig_env.py:368-377) for one env per wave
+// ------------------------------------------------------------------------------------------------
+#define MODE_STEP 0
+#define MODE_OBS 1
+
+template <int MODE>
+__global__ __launch_bounds__(64) void k_env_post(const StepParams P, const int64_t *__restrict__ env_ids, int count) {
+    extern __shared__ __align__(16) float s_dyn[]; // [obs_dim rounded to 4][tile]
+    __shared__ DevTables s_tab;
+    __shared__ float4 s_q[8][16];   // row r: quats 0..14 (0 = root), slot 15 = root position
+    __shared__ float4 s_bp[8][16];  // FK body positions per row
+    __shared__ float4 s_br[2][16];  // body rotations of char/ref (tracking error only)
+    __shared__ float4 s_cbp[16];    // simulator rigid-body positions of the character
+    __shared__ float4 s_rpo[8];     // per target row: heading-frame root offset
+    __shared__ float s_cdof[PARC_MAX_DOFS], s_cdofv[PARC_MAX_DOFS];
+    __shared__ float4 s_refvel[12]; // record float4 #20..: root_vel, root_ang_vel, dof_vel
+    __shared__ float s_refct[16];
+    __shared__ float s_cfn[16];
+    __shared__ float s_red[4][64];
+    __shared__ int s_bi0[8], s_bi1[8];
+    __shared__ float s_bb[8];
+
+    const int lane = threadIdx.x;
+    float *s_obs = s_dyn;
+    const int obs_pad = (P.obs_dim + 3) & ~3;
+    float *s_tile = s_dyn + obs_pad;
+
+    for (int i = lane; i < (int)(sizeof(DevTables) / 4); i += 64) ((int *)&s_tab)[i] = ((const int *)P.tables)[i];
+    __syncthreads();
+
+    const int B = P.B, D = P.D, S = P.S, K = P.K;
+
+    for (int it = blockIdx.x; it < count; it += gridDim.x) {
+        int e = env_ids ? (int)env_ids[it] : it;
+        e = __builtin_amdgcn_readfirstlane(e);
+
+        // ---- bookkeeping + time (ig_env.py:391-394, dm_env.py:547-552) -------------------------
+        const int mid = P.buf.motion_ids[e];
+        const int tid = P.buf.terrain_ids[e];
+        const float toff = P.buf.time_offsets[e];
+        int ts = P.buf.timestep[e];
+        if (MODE == MODE_STEP) ts += 1;
+        const float time = P.dt_f * (float)ts;
+        const float mt = time + toff;
+        const MotionMeta meta = P.meta[mid];
+        const float eox = P.env_offsets[3 * e + 0], eoy = P.env_offsets[3 * e + 1], eoz = P.env_offsets[3 * e + 2];
+        const float *mo = P.motion_offsets + 2 * ((size_t)mid * P.T + tid);
+        const float offx = mo[0] - eox, offy = mo[1] - eoy; // dm_env.py:556
+
+        // ---- character root state, heading ----------------------------------------------------
+        const float *crp = P.buf.char_root_pos + 3 * (size_t)e;
+        const float *crr = P.buf.char_root_rot + 4 * (size_t)e;
+        const V3 root_pos = mk3(crp[0], crp[1], crp[2]);
+        const Q4 root_rot = mk4(crr[0], crr[1], crr[2], crr[3]);
+        const float heading = calc_heading(root_rot);
+        const Q4 hinv = heading_quat_inv(heading);
+
+        // dof state -> LDS, dof velocities straight into the observation row
+        if (lane < D) {
+            float dp = P.buf.char_dof_pos[(size_t)e * D + lane];
+            float dv = P.buf.char_dof_vel[(size_t)e * D + lane];
+            s_cdof[lane] = dp;
+            s_cdofv[lane] = dv;
+            s_obs[P.off_dofvel + lane] = dv;
+        }
+        // root velocities in the heading frame (ig_char_env.py:593-597)
+        if (lane == 62 || lane == 63) {
+            const float *v = (lane == 62 ? P.buf.char_root_vel : P.buf.char_root_ang_vel) + 3 * (size_t)e;
+            V3 r = quat_rotate(hinv, mk3(v[0], v[1], v[2]));
+            int o = lane == 62 ? 6 : 9;
+            s_obs[o + 0] = r.x; s_obs[o + 1] = r.y; s_obs[o + 2] = r.z;
+        }
+        // contact flags + clamped force norms (ig_parkour_env.py:655-662, mgdm_dm_util.py:505-508)
+        if (lane >= 32 && lane < 32 + B) {
+            int b = lane - 32;
+            const float *f = P.buf.contact_forces + 3 * ((size_t)e * B + b);
+            float n = norm3(mk3(f[0], f[1], f[2]));
+            s_obs[P.off_cc + b] = n > 1e-5f ? 1.f : 0.f;
+            s_cfn[b] = fminf(n, 1.0f);
+        }
+        if (!P.body_pos_from_fk && lane >= 48 && lane < 48 + B) {
+            int b = lane - 48;
+            const float *p = P.buf.char_body_pos + 3 * ((size_t)e * B + b);
+            s_cbp[b] = make_float4(p[0], p[1], p[2], 0.f);
+        }
+        __syncthreads();
+
+        // ---- 8 rows x 16 lanes: quaternions of char / ref / targets + tan-norm observations ------
+        for (int p = 0; p < 2; ++p) {
+            const int r = p * 4 + (lane >> 4);
+            const int i = lane & 15;
+            if (r < 2 + S) {
+                float4 res = make_float4(0.f, 0.f, 0.f, 1.f);
+                if (r == 0) { // character: dof -> quat (kin_char_model.py:586)
+                    if (i == 0) res = root_rot;
+                    else if (i == 15) res = make_float4(root_pos.x, root_pos.y, root_pos.z, 0.f);
+                    else if (i < B) res = joint_dof_to_rot(s_tab.jtype[i], s_tab.axis[i], &s_cdof[s_tab.dof_idx[i]]);
+                } else { // reference motion sample (motion_lib.py:94-128)
+                    const int s = r - 1;
+                    const float t = s == 0 ? mt : mt + s_tab.tstep[s - 1];
+                    const Blend bl = frame_blend(meta, t);
+                    const float4 *r0 = P.records + (size_t)bl.i0 * REC_F4;
+                    const float4 *r1 = P.records + (size_t)bl.i1 * REC_F4;
+                    const float4 A = r0[i], Bv = r1[i];
+                    if (i == 15) {
+                        const float a = 1.0f - bl.b;
+                        res.x = a * A.x + bl.b * Bv.x;
+                        res.y = a * A.y + bl.b * Bv.y;
+                        res.z = a * A.z + bl.b * Bv.z;
+                        res.w = 0.f;
+                        if (meta.loop == PARC_LOOP_WRAP) { // _calc_loop_offset :440
+                            const float ph = floorf(t / meta.length);
+                            res.x = res.x + ph * meta.dx; res.y = res.y + ph * meta.dy; res.z = res.z + ph * meta.dz;
+                        }
+                        res.x = res.x + offx; // _move_to_motion_terrain dm_env.py:554
+                        res.y = res.y + offy;
+                        s_bi0[s] = bl.i0; s_bi1[s] = bl.i1; s_bb[s] = bl.b;
+                    } else if (i < B) {
+                        res = slerp(A, Bv, bl.b);
+                    }
+                }
+                s_q[r][i] = res;
+                if (r == 1) { // optional mirrors of the reference's ref_* tensors
+                    if (i == 0 && P.buf.ref_root_rot) *(float4 *)(P.buf.ref_root_rot + 4 * (size_t)e) = res;
+                    if (i >= 1 && i < B && P.buf.ref_joint_rot) *(float4 *)(P.buf.ref_joint_rot + 4 * ((size_t)e * P.J + i - 1)) = res;
+                    if (i == 15 && P.buf.ref_root_pos) {
+                        float *o = P.buf.ref_root_pos + 3 * (size_t)e;
+                        o[0] = res.x; o[1] = res.y; o[2] = res.z;
+                    }
+                } else { // observation pieces (ig_char_env.py:582, mgdm_dm_util.py:405)
+                    const int base = r == 0 ? 0 : P.off_tar + (r - 2) * P.tar_w;
+                    if (i < B) {
+                        const Q4 qq = i == 0 ? quat_mul(hinv, res) : res;
+                        float tn[6];
+                        quat_to_tan_norm(qq, tn);
+                        const int o = r == 0 ? (i == 0 ? 0 : 12 + 6 * (i - 1)) : base + 3 + 6 * i;
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) s_obs[o + c] = tn[c];
+                    } else if (i == 15 && r >= 2) {
+                        V3 rpo = quat_rotate(hinv, mk3(res.x - root_pos.x, res.y - root_pos.y, res.z - root_pos.z));
+                        s_obs[base + 0] = rpo.x; s_obs[base + 1] = rpo.y; s_obs[base + 2] = rpo.z;
+                        s_rpo[r] = make_float4(rpo.x, rpo.y, rpo.z, 0.f);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- contacts of the 1+S samples and the velocity block of sample 0 ---------------------
+        if (lane < 4 * (1 + S)) {
+            const int s = lane >> 2, c = lane & 3;
+            const float b = s_bb[s], a = 1.0f - b;
+            const float4 A = P.records[(size_t)s_bi0[s] * REC_F4 + REC_Q_CONTACT + c];
+            const float4 Bv = P.records[(size_t)s_bi1[s] * REC_F4 + REC_Q_CONTACT + c];
+            const float v[4] = {a * A.x + b * Bv.x, a * A.y + b * Bv.y, a * A.z + b * Bv.z, a * A.w + b * Bv.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int bd = 4 * c + k;
+                if (bd < B) {
+                    if (s == 0) {
+                        s_refct[bd] = v[k];
+                        if (P.buf.ref_contacts) P.buf.ref_contacts[(size_t)e * B + bd] = v[k];
+                    } else {
+                        s_obs[P.off_tarc + (s - 1) * B + bd] = v[k];
+                    }
+                }
+            }
+        } else if (lane >= 32 && lane < 32 + 2 + (D + 3) / 4) { // velocities come from frame idx0 un-interpolated (:103-109)
+            const int c = lane - 32;
+            const float4 v = P.records[(size_t)s_bi0[0] * REC_F4 + REC_Q_VEL + c];
+            s_refvel[c] = v;
+            if (c == 0 && P.buf.ref_root_vel) { float *o = P.buf.ref_root_vel + 3 * (size_t)e; o[0] = v.x; o[1] = v.y; o[2] = v.z; }
+            if (c == 1 && P.buf.ref_root_ang_vel) { float *o = P.buf.ref_root_ang_vel + 3 * (size_t)e; o[0] = v.x; o[1] = v.y; o[2] = v.z; }
+            if (c >= 2 && P.buf.ref_dof_vel) {
+                const float vv[4] = {v.x, v.y, v.z, v.w};
+                for (int k = 0; k < 4; ++k) { int d = 4 * (c - 2) + k; if (d < D) P.buf.ref_dof_vel[(size_t)e * D + d] = vv[k]; }
+            }
+        }
+
+        // ---- FK: row k = lane>>3, root-to-leaf chain c = lane&7 (kin_char_model.py:617-649) -----
+        {
+            const int k = lane >> 3, c = lane & 7;
+            if (k < 2 + S) {
+                Q4 prot = s_q[k][0];
+                float4 pp = s_q[k][15];
+                V3 ppos = mk3(pp.x, pp.y, pp.z);
+                if (c == 0) {
+                    s_bp[k][0] = make_float4(ppos.x, ppos.y, ppos.z, 0.f);
+                    if (k < 2 && P.tracking) s_br[k][0] = prot;
+                }
+#pragma unroll 1
+                for (int d = 0; d < PARC_MAX_FK_DEPTH; ++d) {
+                    const int b = s_tab.fk_paths[c][d];
+                    if (b < 0) break;
+                    const V3 wt = quat_rotate(prot, mk3(s_tab.lt[b][0], s_tab.lt[b][1], s_tab.lt[b][2]));
+                    ppos = mk3(ppos.x + wt.x, ppos.y + wt.y, ppos.z + wt.z);
+                    const Q4 lr = mk4(s_tab.lr[b][0], s_tab.lr[b][1], s_tab.lr[b][2], s_tab.lr[b][3]);
+                    prot = quat_mul(prot, quat_mul(lr, s_q[k][b]));
+                    s_bp[k][b] = make_float4(ppos.x, ppos.y, ppos.z, 0.f);
+                    if (k < 2 && P.tracking) s_br[k][b] = prot;
+                }
+            }
+        }
+        __syncthreads();
+        if (P.body_pos_from_fk && lane < B) s_cbp[lane] = s_bp[0][lane];
+
+        // ---- key-body observations (ig_char_env.py:603-617, mgdm_dm_util.py:415-440) ------------
+        if (lane < 8 * (1 + S)) {
+            const int row = lane >> 3, kk = lane & 7; // row 0 = char, 1.. = target rows 2..
+            if (kk < K) {
+                const int b = s_tab.key_ids[kk];
+                if (row == 0) {
+                    const float4 kp = s_bp[0][b];
+                    const V3 rl = quat_rotate(hinv, mk3(kp.x - root_pos.x, kp.y - root_pos.y, kp.z - root_pos.z));
+                    const int o = P.off_key + 3 * kk;
+                    s_obs[o] = rl.x; s_obs[o + 1] = rl.y; s_obs[o + 2] = rl.z;
+                } else {
+                    const int r = row + 1;
+                    const float4 kp = s_bp[r][b], tr = s_q[r][15], rpo = s_rpo[r];
+                    const V3 rl = quat_rotate(hinv, mk3(kp.x - tr.x, kp.y - tr.y, kp.z - tr.z));
+                    const int o = P.off_tar + (r - 2) * P.tar_w + 3 + 6 * B + 3 * kk;
+                    s_obs[o] = rl.x + rpo.x; s_obs[o + 1] = rl.y + rpo.y; s_obs[o + 2] = rl.z + rpo.z;
+                }
+            }
+        }
+
+        // ---- height rays (mgdm_dm_util.py:128-145; terrain_util.py:146-156) ---------------------
+        {
+            const float gx = root_pos.x + eox, gy = root_pos.y + eoy, gz = root_pos.z + eoz; // ig_parkour_env.py:522
+            const int tr = P.tile_r, TW = 2 * tr + 1;
+            const int ox = cell_index(gx, P.min_x, P.dx) - tr, oy = cell_index(gy, P.min_y, P.dy) - tr;
+            for (int idx = lane; idx < TW * TW; idx += 64) {
+                const int a = idx / TW, bq = idx - a * TW;
+                const int cx = min(max(ox + a, 0), P.X - 1), cy = min(max(oy + bq, 0), P.Y - 1);
+                s_tile[idx] = P.hf[(size_t)cx * P.Y + cy];
+            }
+            __syncthreads();
+            const float ch = cosf(heading), sh = sinf(heading);
+            for (int r = lane; r < P.R; r += 64) {
+                const float rx = P.ray_points[2 * r], ry = P.ray_points[2 * r + 1];
+                const float px = (rx * ch - ry * sh) + gx; // rotate_2d_vec torch_util.py:651
+                const float py = (rx * sh + ry * ch) + gy;
+                const int ix = cell_index(px, P.min_x, P.dx), iy = cell_index(py, P.min_y, P.dy);
+                const int a = ix - ox, bq = iy - oy;
+                float h;
+                if (a >= 0 && a < TW && bq >= 0 && bq < TW) {
+                    h = s_tile[a * TW + bq];
+                } else { // outside the staged tile (cannot happen for the default fan; kept for safety)
+                    const int cx = min(max(ix, 0), P.X - 1), cy = min(max(iy, 0), P.Y - 1);
+                    h = P.hf[(size_t)cx * P.Y + cy];
+                }
+                h = h - gz;
+                h = fminf(fmaxf(h, P.min_obs_h), P.max_obs_h);
+                s_obs[P.off_hf + r] = h;
+                if (P.buf.ray_hfs) P.buf.ray_hfs[(size_t)e * P.R + r] = h;
+            }
+        }
+
+        if (MODE == MODE_STEP) {
+            // ---- reward terms (mgdm_dm_util.py:270-333, 498-518) ------------------------------
+            if (lane < P.J) { // pose: angle of ref (x) conj(char) per joint
+                const float d = quat_diff_angle(s_q[0][1 + lane], s_q[1][1 + lane]);
+                s_red[0][lane] = s_tab.joint_err_w[lane] * d * d;
+            }
+            if (lane < D) {
+                const float v = ((const float *)s_refvel)[8 + lane] - s_cdofv[lane];
+                s_red[1][lane] = s_tab.dof_err_w[lane] * v * v;
+            }
+            if (lane >= 48 && lane < 48 + K) { // key positions: simulator bodies vs reference FK (ig_parkour_env.py:987)
+                const int b = s_tab.key_ids[lane - 48];
+                const float4 kp = s_cbp[b], tk = s_bp[1][b], trp = s_q[1][15];
+                const float dx = (tk.x - trp.x) - (kp.x - root_pos.x);
+                const float dy = (tk.y - trp.y) - (kp.y - root_pos.y);
+                const float dz = (tk.z - trp.z) - (kp.z - root_pos.z);
+                s_red[2][lane - 48] = dx * dx + dy * dy + dz * dz;
+            }
+            if (lane >= 32 && lane < 32 + B) { // contact term
+                const int b = lane - 32;
+                const float tar = s_refct[b], f = s_cfn[b];
+                float cr = -(1.0f - tar) * f;
+                cr = cr + tar * f;
+                s_red[3][b] = s_tab.contact_w[b] * cr;
+            }
+            // ---- early termination (mgdm_dm_util.py:335-402) ------------------------------------
+            bool bad = false;
+            if (lane >= 1 && lane < B) {
+                const float4 bp = s_cbp[lane], b0 = s_cbp[0], tp = s_bp[1][lane], t0 = s_bp[1][0];
+                const float dx = (tp.x - t0.x) - (bp.x - b0.x);
+                const float dy = (tp.y - t0.y) - (bp.y - b0.y);
+                const float dz = (tp.z - t0.z) - (bp.z - b0.z);
+                const float lim = s_tab.pose_term_dist[lane - 1];
+                bad = (dx * dx + dy * dy + dz * dz) > lim * lim;
+            }
+            const bool pose_fail_any = __ballot(bad) != 0ull;
+            __syncthreads();
+
+            if (lane == 0) {
+                float pose_err = 0.f, vel_err = 0.f, key_err = 0.f, csum = 0.f;
+                for (int j = 0; j < P.J; ++j) pose_err = pose_err + s_red[0][j];
+                for (int d = 0; d < D; ++d) vel_err = vel_err + s_red[1][d];
+                for (int k = 0; k < K; ++k) key_err = key_err + s_red[2][k];
+                for (int b = 0; b < B; ++b) csum = csum + s_red[3][b];
+                const float4 trp = s_q[1][15];
+                const Q4 trr = s_q[1][0];
+                float rdx = trp.x - root_pos.x, rdy = trp.y - root_pos.y, rdz = trp.z - root_pos.z;
+                if (!P.track_root) { rdx = 0.f; rdy = 0.f; }
+                if (!P.track_root_h) rdz = 0.f;
+                const float root_pos_err = rdx * rdx + rdy * rdy + rdz * rdz;
+                const float *rv = P.buf.char_root_vel + 3 * (size_t)e, *rav = P.buf.char_root_ang_vel + 3 * (size_t)e;
+                const float4 tv = s_refvel[0], tav = s_refvel[1];
+                float rre = quat_diff_angle(root_rot, trr);
+                const float root_rot_angle = rre;
+                rre = rre * rre;
+                float d0 = tv.x - rv[0], d1 = tv.y - rv[1], d2 = tv.z - rv[2];
+                const float rve = d0 * d0 + d1 * d1 + d2 * d2;
+                d0 = tav.x - rav[0]; d1 = tav.y - rav[1]; d2 = tav.z - rav[2];
+                const float rave = d0 * d0 + d1 * d1 + d2 * d2;
+                const float pose_r = expf(-0.25f * pose_err);
+                const float vel_r = expf(-0.01f * vel_err);
+                const float root_pose_r = expf(-5.0f * (root_pos_err + 0.1f * rre));
+                const float root_vel_r = expf(-1.0f * (rve + 0.1f * rave));
+                const float key_pos_r = expf(-10.0f * key_err);
+                float rew = P.pose_w * pose_r + P.vel_w * vel_r + P.root_pos_w * root_pose_r + P.root_vel_w * root_vel_r +
+                            P.key_pos_w * key_pos_r;
+                const float contact_pen = csum / (float)B; // torch.mean over bodies (ig_parkour_env.py:1033)
+                rew = rew + contact_pen;
+                P.buf.reward[e] = rew;
+                if (P.buf.reward_terms) {
+                    float *rt = P.buf.reward_terms;
+                    const size_t N = (size_t)P.N;
+                    rt[0 * N + e] = pose_r; rt[1 * N + e] = vel_r; rt[2 * N + e] = root_pose_r; rt[3 * N + e] = root_vel_r;
+                    rt[4 * N + e] = key_pos_r; rt[5 * N + e] = contact_pen; rt[6 * N + e] = rew;
+                }
+                // done (compute_done + DeepMimicEnv.update_done dm_env.py:628-665)
+                int done = PARC_DONE_NULL;
+                if (time >= P.episode_length) done = PARC_DONE_TIME;
+                if (P.early_term) {
+                    bool failed = false;
+                    if (P.pose_term) {
+                        bool pf = pose_fail_any;
+                        if (P.track_root) {
+                            const float4 b0 = s_cbp[0], t0 = s_bp[1][0];
+                            const float ex = b0.x - t0.x, ey = b0.y - t0.y, ez = b0.z - t0.z;
+                            pf = pf || (ex * ex + ey * ey + ez * ez) > P.root_pos_term_sq;
+                            pf = pf || fabsf(root_rot_angle) > P.root_rot_term;
+                        }
+                        failed = pf;
+                    }
+                    if (!(time > 1e-5f)) failed = false;
+                    if (failed) done = PARC_DONE_FAIL;
+                }
+                const bool motion_end = (mt >= meta.length) && (meta.loop != PARC_LOOP_WRAP);
+                unsigned char code = 0;
+                if (done != PARC_DONE_NULL || motion_end) code = (done == PARC_DONE_FAIL) ? 1 : 2;
+                if (motion_end) done = PARC_DONE_FAIL;
+                P.buf.done[e] = done;
+                P.ema_code[e] = code;
+                if (code) { const int slot = atomicAdd(P.done_count, 1); P.done_list[slot] = e; }
+                P.buf.timestep[e] = ts;
+                if (P.buf.time) P.buf.time[e] = time;
+            }
+
+            // optional outputs: ref body positions / dof positions, character FK bodies, tracking error
+            if (P.buf.ref_body_pos && lane < B) {
+                float *o = P.buf.ref_body_pos + 3 * ((size_t)e * B + lane);
+                const float4 v = s_bp[1][lane];
+                o[0] = v.x; o[1] = v.y; o[2] = v.z;
+            }
+            if (P.buf.ref_dof_pos && lane >= 1 && lane < B) { // kin_char_model.py:601
+                const int ty = s_tab.jtype[lane];
+                float out3[3] = {0.f, 0.f, 0.f};
+                joint_rot_to_dof(ty, s_tab.axis[lane], s_q[1][lane], out3);
+                const int nd = ty == PARC_JOINT_HINGE ? 1 : (ty == PARC_JOINT_SPHERICAL ? 3 : 0);
+                for (int k = 0; k < nd; ++k) P.buf.ref_dof_pos[(size_t)e * D + s_tab.dof_idx[lane] + k] = out3[k];
+            }
+            if (P.tracking && P.buf.tracking_error) { // mgdm_dm_util.py:521-553
+                if (lane < B) {
+                    s_red[0][lane] = fabsf(quat_diff_angle(s_br[0][lane], s_br[1][lane]));
+                    const float4 cb = s_bp[0][lane], rb = s_bp[1][lane], trp = s_q[1][15];
+                    const V3 dd = mk3((rb.x - trp.x) - (cb.x - root_pos.x), (rb.y - trp.y) - (cb.y - root_pos.y),
+                                      (rb.z - trp.z) - (cb.z - root_pos.z));
+                    s_red[1][lane] = norm3(dd);
+                }
+                if (lane < D) s_red[2][lane] = fabsf(((const float *)s_refvel)[8 + lane] - s_cdofv[lane]);
+                __syncthreads();
+                if (lane == 0) {
+                    float pe = 0.f, bpe = 0.f, dve = 0.f;
+                    for (int b = 0; b < B; ++b) { pe = pe + s_red[0][b]; bpe = bpe + s_red[1][b]; }
+                    for (int d = 0; d < D; ++d) dve = dve + s_red[2][d];
+                    const float4 trp = s_q[1][15];
+                    const float *rv = P.buf.char_root_vel + 3 * (size_t)e, *rav = P.buf.char_root_ang_vel + 3 * (size_t)e;
+                    const float4 tv = s_refvel[0], tav = s_refvel[1];
+                    float *te = P.buf.tracking_error + 7 * (size_t)e;
+                    te[0] = norm3(mk3(trp.x - root_pos.x, trp.y - root_pos.y, trp.z - root_pos.z));
+                    te[1] = fabsf(quat_diff_angle(root_rot, s_q[1][0]));
+                    te[2] = bpe / (float)B;
+                    te[3] = pe / (float)B;
+                    te[4] = dve / (float)D;
+                    te[5] = (fabsf(tv.x - rv[0]) + fabsf(tv.y - rv[1]) + fabsf(tv.z - rv[2])) / 3.f;
+                    te[6] = (fabsf(tav.x - rav[0]) + fabsf(tav.y - rav[1]) + fabsf(tav.z - rav[2])) / 3.f;
+                }
+            }
+        }
+        if (P.body_pos_from_fk && P.buf.char_body_pos && lane < B) {
+            float *o = P.buf.char_body_pos + 3 * ((size_t)e * B + lane);
+            const float4 v = s_bp[0][lane];
+            o[0] = v.x; o[1] = v.y; o[2] = v.z;
+        }
+        __syncthreads();
+
+        // ---- stream the observation row out: 16 bytes per lane per store -------------------------
+        {
+            float *orow = P.buf.obs + (size_t)e * P.obs_dim;
+            if ((P.obs_dim & 3) == 0) {
+                const float4 *src = (const float4 *)s_obs;
+                float4 *dst = (float4 *)orow;
+                for (int i = lane; i < (P.obs_dim >> 2); i += 64) dst[i] = src[i];
+            } else {
+                for (int i = lane; i < P.obs_dim; i += 64) orow[i] = s_obs[i];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// curriculum: sequential fail-rate EMA in env order (dm_env.py:646-660), exact op order per motion
+// ------------------------------------------------------------------------------------------------
+#define CUR_FAST_MAX 2048
+__global__ __launch_bounds__(1024) void k_curriculum(const unsigned char *__restrict__ ema_code, const int *__restrict__ motion_ids,
+                                                     int *done_list, int *done_count, float *fail_rates, int N, float w) {
+    __shared__ unsigned long long s_key[CUR_FAST_MAX];
+    __shared__ unsigned long long s_sorted[CUR_FAST_MAX];
+    const int k = *done_count;
+    const float keep = (float)(1.0 - (double)w);
+    if (k == 0) return;
+    if (k <= CUR_FAST_MAX) {
+        for (int i = threadIdx.x; i < k; i += blockDim.x) {
+            const int e = done_list[i];
+            s_key[i] = ((unsigned long long)(unsigned)motion_ids[e] << 32) | ((unsigned long long)(unsigned)e << 1) |
+                       (unsigned long long)(ema_code[e] == 1 ? 1 : 0);
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < k; i += blockDim.x) { // rank sort: keys are unique (env id inside)
+            const unsigned long long key = s_key[i];
+            int rank = 0;
+            for (int j = 0; j < k; ++j) rank += (s_key[j] < key) ? 1 : 0;
+            s_sorted[rank] = key;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < k; i += blockDim.x) {
+            const unsigned m = (unsigned)(s_sorted[i] >> 32);
+            if (i == 0 || (unsigned)(s_sorted[i - 1] >> 32) != m) { // segment head: apply the chain in env order
+                float f = fail_rates[m];
+                for (int j = i; j < k && (unsigned)(s_sorted[j] >> 32) == m; ++j)
+                    f = (s_sorted[j] & 1ull) ? (f * keep + w) : (f * keep);
+                fail_rates[m] = f;
+            }
+        }
+    } else if (threadIdx.x == 0) { // rare (synchronised time-outs): the reference's own sequential loop
+        for (int e = 0; e < N; ++e) {
+            const unsigned char c = ema_code[e];
+            if (c) {
+                const int m = motion_ids[e];
+                const float f = fail_rates[m];
+                fail_rates[m] = c == 1 ? (f * keep + w) : (f * keep);
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *done_count = 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// motion library preparation (motion_lib.py:305-327, kin_char_model.py:651-693): one thread per frame
+// ------------------------------------------------------------------------------------------------
+struct PrepParams {
+    int F, B, J, D;
+    const float *root_pos, *root_rot, *joint_rot, *contacts;
+    const int *frame_motion; // [F]
+    const MotionMeta *meta;
+    const DevTables *tables;
+    float4 *records;
+};
+
+__global__ void k_motion_prep(const PrepParams P) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= P.F) return;
+    const int m = P.frame_motion[f];
+    const MotionMeta meta = P.meta[m];
+    const DevTables *T = P.tables;
+    float4 *rec = P.records + (size_t)f * REC_F4;
+    float *recf = (float *)rec;
+    for (int i = 0; i < 128; ++i) recf[i] = 0.f;
+    const float *rr = P.root_rot + 4 * (size_t)f;
+    rec[0] = make_float4(rr[0], rr[1], rr[2], rr[3]);
+    for (int j = 0; j < P.J; ++j) {
+        const float *q = P.joint_rot + 4 * ((size_t)f * P.J + j);
+        rec[1 + j] = make_float4(q[0], q[1], q[2], q[3]);
+    }
+    const float *rp = P.root_pos + 3 * (size_t)f;
+    rec[REC_Q_POS] = make_float4(rp[0], rp[1], rp[2], 0.f);
+    for (int b = 0; b < P.B; ++b) recf[4 * REC_Q_CONTACT + b] = P.contacts ? P.contacts[(size_t)f * P.B + b] : 0.f;
+    // velocities: finite difference (f0, f0+1); the last frame repeats the previous pair
+    const int local = f - meta.start;
+    int f0 = f;
+    if (local == meta.nframes - 1) f0 = f - 1;
+    if (meta.nframes < 2) return;
+    const float fps = meta.fps;
+    const float dt = (float)(1.0 / (double)meta.fps);
+    const float *p0 = P.root_pos + 3 * (size_t)f0, *p1 = p0 + 3;
+    recf[4 * REC_Q_VEL + 0] = fps * (p1[0] - p0[0]);
+    recf[4 * REC_Q_VEL + 1] = fps * (p1[1] - p0[1]);
+    recf[4 * REC_Q_VEL + 2] = fps * (p1[2] - p0[2]);
+    const float *r0 = P.root_rot + 4 * (size_t)f0, *r1 = r0 + 4;
+    const Q4 dq = quat_mul(mk4(r1[0], r1[1], r1[2], r1[3]), quat_conj(mk4(r0[0], r0[1], r0[2], r0[3]))); // quat_diff :454
+    const V3 ev = quat_to_exp_map(dq);
+    recf[4 * (REC_Q_VEL + 1) + 0] = fps * ev.x;
+    recf[4 * (REC_Q_VEL + 1) + 1] = fps * ev.y;
+    recf[4 * (REC_Q_VEL + 1) + 2] = fps * ev.z;
+    float *dv = recf + 4 * (REC_Q_VEL + 2);
+    for (int j = 1; j < P.B; ++j) { // compute_dof_vel kin_char_model.py:661
+        const float *a = P.joint_rot + 4 * ((size_t)f0 * P.J + j - 1), *b = a + 4 * P.J;
+        const Q4 d = quat_normalize(quat_mul(quat_conj(mk4(a[0], a[1], a[2], a[3])), mk4(b[0], b[1], b[2], b[3])));
+        const int ty = T->jtype[j];
+        if (ty == PARC_JOINT_HINGE) {
+            V3 x = quat_to_exp_map(d);
+            x = mk3(x.x / dt, x.y / dt, x.z / dt);
+            dv[T->dof_idx[j]] = T->axis[j][0] * x.x + T->axis[j][1] * x.y + T->axis[j][2] * x.z;
+        } else if (ty == PARC_JOINT_SPHERICAL) {
+            const V3 x = quat_to_exp_map(d);
+            dv[T->dof_idx[j] + 0] = x.x / dt;
+            dv[T->dof_idx[j] + 1] = x.y / dt;
+            dv[T->dof_idx[j] + 2] = x.z / dt;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// one-thread-per-item operators (cfg-1 plumbing, reset): calc_motion_frame, dof<->rot, FK
+// ------------------------------------------------------------------------------------------------
+struct FrameOut { float *root_pos, *root_rot, *root_vel, *root_ang_vel, *joint_rot, *dof_vel, *contacts; };
+
+__device__ void motion_frame_thread(const float4 *records, const MotionMeta meta, float t, int B, int J, int D, size_t o,
+                                    const FrameOut &F) {
+    const Blend bl = frame_blend(meta, t);
+    const float4 *r0 = records + (size_t)bl.i0 * REC_F4, *r1 = records + (size_t)bl.i1 * REC_F4;
+    const float b = bl.b, a = 1.0f - b;
+    {
+        const float4 A = r0[REC_Q_POS], Bv = r1[REC_Q_POS];
+        float x = a * A.x + b * Bv.x, y = a * A.y + b * Bv.y, z = a * A.z + b * Bv.z;
+        if (meta.loop == PARC_LOOP_WRAP) {
+            const float ph = floorf(t / meta.length);
+            x = x + ph * meta.dx; y = y + ph * meta.dy; z = z + ph * meta.dz;
+        }
+        F.root_pos[3 * o] = x; F.root_pos[3 * o + 1] = y; F.root_pos[3 * o + 2] = z;
+    }
+    const Q4 rr = slerp(r0[0], r1[0], b);
+    *(float4 *)(F.root_rot + 4 * o) = rr;
+    for (int j = 0; j < J; ++j) *(float4 *)(F.joint_rot + 4 * (o * J + j)) = slerp(r0[1 + j], r1[1 + j], b);
+    const float *v = (const float *)(r0 + REC_Q_VEL);
+    if (F.root_vel) { F.root_vel[3 * o] = v[0]; F.root_vel[3 * o + 1] = v[1]; F.root_vel[3 * o + 2] = v[2]; }
+    if (F.root_ang_vel) { F.root_ang_vel[3 * o] = v[4]; F.root_ang_vel[3 * o + 1] = v[5]; F.root_ang_vel[3 * o + 2] = v[6]; }
+    if (F.dof_vel) for (int d = 0; d < D; ++d) F.dof_vel[o * D + d] = v[8 + d];
+    if (F.contacts) {
+        const float *c0 = (const float *)(r0 + REC_Q_CONTACT), *c1 = (const float *)(r1 + REC_Q_CONTACT);
+        for (int k = 0; k < B; ++k) F.contacts[o * B + k] = a * c0[k] + b * c1[k];
+    }
+}
+
+__global__ void k_calc_motion_frame(const float4 *records, const MotionMeta *meta, const int *ids, const float *times, int n,
+                                    int B, int J, int D, FrameOut F) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    motion_frame_thread(records, meta[ids[i]], times[i], B, J, D, (size_t)i, F);
+}
+
+__global__ void k_dof_to_rot(const DevTables *T, const float *dof, float *jr, int n, int B, int D) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int j = 1; j < B; ++j)
+        *(float4 *)(jr + 4 * ((size_t)i * (B - 1) + j - 1)) = joint_dof_to_rot(T->jtype[j], T->axis[j], dof + (size_t)i * D + T->dof_idx[j]);
+}
+
+__global__ void k_rot_to_dof(const DevTables *T, const float *jr, float *dof, int n, int B, int D) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int d = 0; d < D; ++d) dof[(size_t)i * D + d] = 0.f;
+    for (int j = 1; j < B; ++j)
+        joint_rot_to_dof(T->jtype[j], T->axis[j], *(const float4 *)(jr + 4 * ((size_t)i * (B - 1) + j - 1)), dof + (size_t)i * D + T->dof_idx[j]);
+}
+
+__device__ void fk_thread(const DevTables *T, int B, V3 root_pos, Q4 root_rot, const float *jr, float *bp, float *br) {
+    Q4 rot[PARC_MAX_BODIES];
+    V3 pos[PARC_MAX_BODIES];
+    rot[0] = root_rot; pos[0] = root_pos;
+    for (int j = 1; j < B; ++j) {
+        const int p = T->parent[j];
+        const V3 wt = quat_rotate(rot[p], mk3(T->lt[j][0], T->lt[j][1], T->lt[j][2]));
+        pos[j] = mk3(pos[p].x + wt.x, pos[p].y + wt.y, pos[p].z + wt.z);
+        const Q4 q = *(const float4 *)(jr + 4 * (j - 1));
+        rot[j] = quat_mul(rot[p], quat_mul(mk4(T->lr[j][0], T->lr[j][1], T->lr[j][2], T->lr[j][3]), q));
+    }
+    for (int j = 0; j < B; ++j) {
+        bp[3 * j] = pos[j].x; bp[3 * j + 1] = pos[j].y; bp[3 * j + 2] = pos[j].z;
+        if (br) *(float4 *)(br + 4 * j) = rot[j];
+    }
+}
+
+__global__ void k_fk(const DevTables *T, const float *root_pos, const float *root_rot, const float *jr, float *bp, float *br,
+                     int n, int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *rp = root_pos + 3 * (size_t)i, *rr = root_rot + 4 * (size_t)i;
+    fk_thread(T, B, mk3(rp[0], rp[1], rp[2]), mk4(rr[0], rr[1], rr[2], rr[3]), jr + 4 * (size_t)i * (B - 1),
+              bp + 3 * (size_t)i * B, br ? br + 4 * (size_t)i * B : nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------
+// reset (dm_env.py:567-592): thread per reset env
+// ------------------------------------------------------------------------------------------------
+struct ResetParams {
+    int B, J, D, T, N;
+    const float4 *records; const MotionMeta *meta; const float *motion_offsets; const float *env_offsets;
+    const DevTables *tables;
+    float *scratch_jr;  // [N][J][4] when ref_joint_rot is not bound
+    ParcEnvBuffers buf;
+};
+
+__global__ void k_reset_with(const ResetParams P, const int64_t *env_ids, int k, const int *motion_ids, const int *terrain_ids,
+                             const float *t0, const float *xy_noise) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k) return;
+    const int e = env_ids ? (int)env_ids[i] : i;
+    const int mid = motion_ids[i], tid = terrain_ids[i];
+    const float t = t0[i];
+    const int B = P.B, J = P.J, D = P.D;
+    P.buf.motion_ids[e] = mid;
+    P.buf.terrain_ids[e] = tid;
+    P.buf.time_offsets[e] = t;
+    // reference frame at t0 -> character state (mgdm_dm_util.py:89-100); ref_* mirrors when bound
+    FrameOut F;
+    F.root_pos = P.buf.char_root_pos; F.root_rot = P.buf.char_root_rot; F.root_vel = P.buf.char_root_vel;
+    F.root_ang_vel = P.buf.char_root_ang_vel; F.dof_vel = P.buf.char_dof_vel;
+    F.joint_rot = P.buf.ref_joint_rot ? P.buf.ref_joint_rot : P.scratch_jr;
+    F.contacts = P.buf.ref_contacts;
+    motion_frame_thread(P.records, P.meta[mid], t, B, J, D, (size_t)e, F);
+    const float *mo = P.motion_offsets + 2 * ((size_t)mid * P.T + tid);
+    const float ox = mo[0] - P.env_offsets[3 * e], oy = mo[1] - P.env_offsets[3 * e + 1];
+    float *crp = P.buf.char_root_pos + 3 * (size_t)e;
+    const float rx = crp[0] + ox, ry = crp[1] + oy, rz = crp[2];
+    const float *jr = F.joint_rot + 4 * (size_t)e * J;
+    float *dof = P.buf.char_dof_pos + (size_t)e * D;
+    for (int d = 0; d < D; ++d) dof[d] = 0.f;
+    for (int j = 1; j < B; ++j)
+        joint_rot_to_dof(P.tables->jtype[j], P.tables->axis[j], *(const float4 *)(jr + 4 * (j - 1)), dof + P.tables->dof_idx[j]);
+    if (P.buf.ref_root_pos) { float *o = P.buf.ref_root_pos + 3 * (size_t)e; o[0] = rx; o[1] = ry; o[2] = rz; }
+    if (P.buf.ref_root_rot) for (int c = 0; c < 4; ++c) P.buf.ref_root_rot[4 * (size_t)e + c] = P.buf.char_root_rot[4 * (size_t)e + c];
+    if (P.buf.ref_root_vel) for (int c = 0; c < 3; ++c) P.buf.ref_root_vel[3 * (size_t)e + c] = P.buf.char_root_vel[3 * (size_t)e + c];
+    if (P.buf.ref_root_ang_vel) for (int c = 0; c < 3; ++c) P.buf.ref_root_ang_vel[3 * (size_t)e + c] = P.buf.char_root_ang_vel[3 * (size_t)e + c];
+    if (P.buf.ref_dof_pos) for (int d = 0; d < D; ++d) P.buf.ref_dof_pos[(size_t)e * D + d] = dof[d];
+    if (P.buf.ref_dof_vel) for (int d = 0; d < D; ++d) P.buf.ref_dof_vel[(size_t)e * D + d] = P.buf.char_dof_vel[(size_t)e * D + d];
+    // add_noise_to_char_state (mgdm_dm_util.py:102-106): xy += scale * U(-1,1) (drawn by the caller / sampler)
+    crp[0] = rx + xy_noise[2 * i];
+    crp[1] = ry + xy_noise[2 * i + 1];
+    // rigid bodies: FK of the new state (PhysX would refresh them one sim step later); contact forces cleared
+    if (P.buf.char_body_pos) {
+        const float *rr = P.buf.char_root_rot + 4 * (size_t)e;
+        fk_thread(P.tables, B, mk3(crp[0], crp[1], crp[2]), mk4(rr[0], rr[1], rr[2], rr[3]), jr, P.buf.char_body_pos + 3 * (size_t)e * B, nullptr);
+    }
+    if (P.buf.contact_forces) for (int c = 0; c < 3 * B; ++c) P.buf.contact_forces[(size_t)e * 3 * B + c] = 0.f;
+    P.buf.timestep[e] = 0;
+    if (P.buf.time) P.buf.time[e] = 0.f;
+    P.buf.done[e] = PARC_DONE_NULL;
+    if (P.buf.ep_num) P.buf.ep_num[e] += 1; // ig_parkour_env.py:826-827
+}
+
+// ---- device RNG for resets: Philox4x32-10 ---------------------------------------------------------
+__device__ __forceinline__ void philox_round(unsigned &c0, unsigned &c1, unsigned &c2, unsigned &c3, unsigned k0, unsigned k1) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
+    const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
+    const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+__device__ __forceinline__ void philox4(unsigned long long seed, unsigned long long ctr_hi, unsigned ctr_lo, float *u4) {
+    unsigned c0 = ctr_lo, c1 = (unsigned)ctr_hi, c2 = (unsigned)(ctr_hi >> 32), c3 = 0x5041524Bu;
+    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+    for (int r = 0; r < 10; ++r) { philox_round(c0, c1, c2, c3, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+    u4[0] = (c0 >> 8) * (1.0f / 16777216.0f); u4[1] = (c1 >> 8) * (1.0f / 16777216.0f);
+    u4[2] = (c2 >> 8) * (1.0f / 16777216.0f); u4[3] = (c3 >> 8) * (1.0f / 16777216.0f);
+}
+
+// weights = clamp(fail_rate, min_w) * motion_weight (dm_env.py:487-490) -> inclusive CDF (one block)
+__global__ __launch_bounds__(1024) void k_build_cdf(const float *fail_rates, const float *motion_weights, float min_w, int M, float *cdf) {
+    __shared__ double s_part[1024];
+    const int per = (M + 1023) / 1024;
+    const int b = threadIdx.x * per, eend = min(M, b + per);
+    double s = 0.0;
+    for (int m = b; m < eend; ++m) s += (double)(fmaxf(fail_rates[m], min_w) * motion_weights[m]);
+    s_part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { double acc = 0.0; for (int i = 0; i < 1024; ++i) { double v = s_part[i]; s_part[i] = acc; acc += v; } }
+    __syncthreads();
+    double acc = s_part[threadIdx.x];
+    for (int m = b; m < eend; ++m) { acc += (double)(fmaxf(fail_rates[m], min_w) * motion_weights[m]); cdf[m] = (float)acc; }
+}
+
+__global__ void k_reset_sample(const int64_t *env_ids, int k, int M, int T, const float *cdf, const MotionMeta *meta,
+                               unsigned long long seed, unsigned long long call, int rand_reset, int demo_mode, float noise_scale,
+                               const float *start_frac, int *motion_ids, int *terrain_ids, float *t0, float *xy_noise) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k) return;
+    const int e = env_ids ? (int)env_ids[i] : i;
+    float u[4], v[4];
+    philox4(seed, call, (unsigned)e * 2u, u);
+    philox4(seed, call, (unsigned)e * 2u + 1u, v);
+    int mid;
+    if (demo_mode) mid = e % M; // dm_env.py:479-480
+    else { // multinomial with replacement == inverse CDF per draw (motion_lib.py:56-60)
+        const float x = u[0] * cdf[M - 1];
+        int lo = 0, hi = M - 1;
+        while (lo < hi) { const int md = (lo + hi) >> 1; if (cdf[md] > x) hi = md; else lo = md + 1; }
+        mid = lo;
+    }
+    motion_ids[i] = mid;
+    terrain_ids[i] = min((int)(u[1] * (float)T), T - 1);                        // torch.randint(high=T)
+    const float len = meta[mid].length;
+    t0[i] = rand_reset ? u[2] * len : len * (start_frac ? start_frac[e] : 0.f); // motion_lib.py:62-72, dm_env.py:500-504
+    xy_noise[2 * i] = noise_scale * (v[0] * 2.0f - 1.0f);                       // mgdm_dm_util.py:103-104
+    xy_noise[2 * i + 1] = noise_scale * (v[1] * 2.0f - 1.0f);
+}
+
+// ================================================================================================
+// host side
+// ================================================================================================
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+
+#define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return fail(PARC_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(_e)); } while (0)
+
+struct ParcEnv {
+    ParcEnvConfig cfg;
+    int B, J, D, K, S, R, N, M = 0, T = 1;
+    int obs_dim;
+    int64_t F = 0;
+    bool bound = false, have_motions = false, have_terrain = false;
+    StepParams sp;
+    DevTables h_tab;
+    DevTables *d_tab = nullptr;
+    float *d_ray = nullptr, *d_env_off = nullptr, *d_hf = nullptr, *d_motion_off = nullptr;
+    float4 *d_records = nullptr;
+    MotionMeta *d_meta = nullptr;
+    std::vector<MotionMeta> h_meta;
+    std::vector<float> h_weights;
+    float *d_weights = nullptr, *d_fail = nullptr, *d_cdf = nullptr;
+    unsigned char *d_ema = nullptr;
+    int *d_done_list = nullptr, *d_done_count = nullptr;
+    int *d_tmp_mid = nullptr, *d_tmp_tid = nullptr;
+    float *d_tmp_t0 = nullptr, *d_tmp_noise = nullptr, *d_scratch_jr = nullptr, *d_start_frac = nullptr;
+    unsigned long long reset_calls = 0;
+    int grid_waves = 0;
+    size_t lds_bytes = 0;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+
+extern "C" const char *parc_last_error(void) { return g_err.c_str(); }
+extern "C" int parc_abi_version(void) { return PARC_ABI_VERSION; }
+
+static void free_dev(ParcEnv *e) {
+    void *ptrs[] = {e->d_tab, e->d_ray, e->d_env_off, e->d_hf, e->d_motion_off, e->d_records, e->d_meta, e->d_weights, e->d_fail,
+                    e->d_cdf, e->d_ema, e->d_done_list, e->d_done_count, e->d_tmp_mid, e->d_tmp_tid, e->d_tmp_t0, e->d_tmp_noise,
+                    e->d_scratch_jr};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (auto &ev : e->ev) if (ev) (void)hipEventDestroy(ev);
+}
+
+extern "C" int parc_env_create(const ParcEnvConfig *cfg, ParcEnv **out) {
+    if (!cfg || !out) return fail(PARC_ERR_INVALID, "null argument");
+    if (cfg->abi_version != PARC_ABI_VERSION || cfg->struct_size != sizeof(ParcEnvConfig))
+        return fail(PARC_ERR_INVALID, "ParcEnvConfig ABI mismatch (abi_version / struct_size)");
+    const ParcCharModel &m = cfg->model;
+    if (m.num_bodies < 2 || m.num_bodies > 15) return fail(PARC_ERR_INVALID, "num_bodies must be in [2,15]");
+    if (m.dof_size < 1 || m.dof_size > PARC_MAX_DOFS) return fail(PARC_ERR_INVALID, "dof_size must be in [1,40]");
+    if (cfg->num_tar_obs_steps < 1 || cfg->num_tar_obs_steps > PARC_MAX_TAR_STEPS) return fail(PARC_ERR_INVALID, "tar_obs_steps: 1..6 entries");
+    if (cfg->num_key_bodies < 0 || cfg->num_key_bodies > PARC_MAX_KEY_BODIES) return fail(PARC_ERR_INVALID, "key_bodies: at most 8");
+    if (cfg->num_envs < 1) return fail(PARC_ERR_INVALID, "num_envs must be >= 1");
+    if (cfg->num_rays < 1 || cfg->num_rays > 4096 || !cfg->ray_points_host) return fail(PARC_ERR_INVALID, "ray fan: 1..4096 points");
+    if (!cfg->env_offsets_host) return fail(PARC_ERR_INVALID, "env_offsets_host is required");
+    for (int b = 1; b < m.num_bodies; ++b)
+        if (m.parent[b] < 0 || m.parent[b] >= b) return fail(PARC_ERR_INVALID, "bodies must be in DFS order (parent < child)");
+    if (cfg->enable_dynamics) return fail(PARC_ERR_INVALID, "enable_dynamics: this build ships the kinematic step only");
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(PARC_ERR_NO_DEVICE, "no HIP device visible");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(PARC_ERR_INVALID, "device ordinal out of range");
+    HIPCHK(hipSetDevice(cfg->device));
+
+    ParcEnv *e = new (std::nothrow) ParcEnv();
+    if (!e) return fail(PARC_ERR_INVALID, "out of host memory");
+    e->cfg = *cfg;
+    e->cfg.ray_points_host = nullptr; e->cfg.env_offsets_host = nullptr;
+    e->B = m.num_bodies; e->J = e->B - 1; e->D = m.dof_size; e->K = cfg->num_key_bodies; e->S = cfg->num_tar_obs_steps;
+    e->R = cfg->num_rays; e->N = cfg->num_envs;
+    const int B = e->B, J = e->J, D = e->D, K = e->K, S = e->S, R = e->R;
+
+    DevTables &t = e->h_tab;
+    memset(&t, 0, sizeof(t));
+    for (int b = 0; b < 16; ++b) { t.parent[b] = -1; t.jtype[b] = PARC_JOINT_FIXED; }
+    for (int b = 0; b < B; ++b) {
+        t.parent[b] = m.parent[b]; t.jtype[b] = m.joint_type[b]; t.dof_idx[b] = m.dof_idx[b];
+        for (int c = 0; c < 3; ++c) { t.axis[b][c] = m.joint_axis[b][c]; t.lt[b][c] = m.local_translation[b][c]; }
+        for (int c = 0; c < 4; ++c) t.lr[b][c] = m.local_rotation[b][c];
+    }
+    for (int p = 0; p < PARC_MAX_FK_PATHS; ++p)
+        for (int d = 0; d < PARC_MAX_FK_DEPTH; ++d) {
+            t.fk_paths[p][d] = m.fk_paths[p][d];
+            if (m.fk_paths[p][d] >= B) { delete e; return fail(PARC_ERR_INVALID, "fk_paths entry out of range"); }
+        }
+    const float dt_f = (float)cfg->control_dt;
+    for (int s = 0; s < S; ++s) t.tstep[s] = dt_f * (float)cfg->tar_obs_steps[s];
+    for (int k = 0; k < K; ++k) {
+        if (cfg->key_body_ids[k] < 0 || cfg->key_body_ids[k] >= B) { delete e; return fail(PARC_ERR_INVALID, "key body id out of range"); }
+        t.key_ids[k] = cfg->key_body_ids[k];
+    }
+    for (int j = 0; j < J; ++j) { t.joint_err_w[j] = cfg->joint_err_w[j]; t.pose_term_dist[j] = cfg->pose_termination_dist[j]; }
+    for (int d = 0; d < D; ++d) t.dof_err_w[d] = cfg->dof_err_w[d];
+    for (int b = 0; b < B; ++b) t.contact_w[b] = cfg->contact_weights[b];
+
+    StepParams &sp = e->sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.N = e->N; sp.B = B; sp.J = J; sp.D = D; sp.K = K; sp.S = S; sp.R = R;
+    // observation layout (ig_parkour_env.py:842-965)
+    sp.off_dofvel = 12 + 6 * J;
+    sp.off_key = sp.off_dofvel + D;
+    sp.off_tar = sp.off_key + 3 * K;
+    sp.tar_w = 3 + 6 + 6 * J + 3 * K;
+    sp.off_tarc = sp.off_tar + S * sp.tar_w;
+    sp.off_cc = sp.off_tarc + S * B;
+    sp.off_hf = sp.off_cc + B;
+    sp.obs_dim = sp.off_hf + R;
+    e->obs_dim = sp.obs_dim;
+    sp.dt_f = dt_f; sp.episode_length = cfg->episode_length; sp.min_obs_h = cfg->min_obs_h; sp.max_obs_h = cfg->max_obs_h;
+    sp.pose_w = cfg->pose_w; sp.vel_w = cfg->vel_w; sp.root_pos_w = cfg->root_pos_w; sp.root_vel_w = cfg->root_vel_w; sp.key_pos_w = cfg->key_pos_w;
+    sp.root_pos_term_sq = (float)((double)cfg->root_pos_termination_dist * (double)cfg->root_pos_termination_dist);
+    sp.root_rot_term = cfg->root_rot_termination_angle;
+    sp.early_term = cfg->enable_early_termination; sp.pose_term = cfg->pose_termination; sp.track_root = cfg->track_root;
+    sp.track_root_h = cfg->track_root_h; sp.tracking = cfg->report_tracking_error; sp.body_pos_from_fk = cfg->body_pos_from_fk;
+    if (!cfg->track_root) { delete e; return fail(PARC_ERR_INVALID, "track_root=false is not supported"); }
+
+    auto up = [&](void **dst, const void *src, size_t bytes) -> hipError_t {
+        hipError_t r = hipMalloc(dst, bytes);
+        if (r != hipSuccess) return r;
+        return src ? hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) : hipMemset(*dst, 0, bytes);
+    };
+    hipError_t r = hipSuccess;
+    const size_t N = (size_t)e->N;
+    if ((r = up((void **)&e->d_tab, &t, sizeof(t))) != hipSuccess ||
+        (r = up((void **)&e->d_ray, cfg->ray_points_host, sizeof(float) * 2 * R)) != hipSuccess ||
+        (r = up((void **)&e->d_env_off, cfg->env_offsets_host, sizeof(float) * 3 * N)) != hipSuccess ||
+        (r = up((void **)&e->d_ema, nullptr, N)) != hipSuccess ||
+        (r = up((void **)&e->d_done_list, nullptr, sizeof(int) * N)) != hipSuccess ||
+        (r = up((void **)&e->d_done_count, nullptr, sizeof(int))) != hipSuccess ||
+        (r = up((void **)&e->d_tmp_mid, nullptr, sizeof(int) * N)) != hipSuccess ||
+        (r = up((void **)&e->d_tmp_tid, nullptr, sizeof(int) * N)) != hipSuccess ||
+        (r = up((void **)&e->d_tmp_t0, nullptr, sizeof(float) * N)) != hipSuccess ||
+        (r = up((void **)&e->d_tmp_noise, nullptr, sizeof(float) * 2 * N)) != hipSuccess ||
+        (r = up((void **)&e->d_scratch_jr, nullptr, sizeof(float) * 4 * J * N)) != hipSuccess) {
+        free_dev(e); delete e;
+        return fail(PARC_ERR_HIP, std::string("device allocation failed: ") + hipGetErrorString(r));
+    }
+    for (auto &ev : e->ev) (void)hipEventCreate(&ev);
+    sp.tables = e->d_tab; sp.ray_points = e->d_ray; sp.env_offsets = e->d_env_off;
+    sp.ema_code = e->d_ema; sp.done_list = e->d_done_list; sp.done_count = e->d_done_count;
+
+    hipDeviceProp_t prop;
+    (void)hipGetDeviceProperties(&prop, cfg->device);
+    e->grid_waves = prop.multiProcessorCount * 16; // persistent waves; each strides over envs
+    *out = e;
+    return PARC_OK;
+}
+
+extern "C" void parc_env_destroy(ParcEnv *e) {
+    if (!e) return;
+    (void)hipSetDevice(e->cfg.device);
+    free_dev(e);
+    delete e;
+}
+
+extern "C" int parc_env_obs_dim(const ParcEnv *e) { return e ? e->obs_dim : PARC_ERR_INVALID; }
+
+extern "C" int parc_env_load_motions(ParcEnv *e, const ParcMotionClips *c) {
+    if (!e || !c || c->num_motions < 1) return fail(PARC_ERR_INVALID, "bad motion clips");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    const int M = c->num_motions, B = e->B, J = e->J;
+    int64_t F = 0;
+    e->h_meta.assign(M, MotionMeta());
+    e->h_weights.assign(M, 0.f);
+    float wsum = 0.f;
+    for (int m = 0; m < M; ++m) {
+        if (c->num_frames_host[m] < 2) return fail(PARC_ERR_INVALID, "every clip needs at least 2 frames");
+        if (c->fps_host[m] <= 0) return fail(PARC_ERR_INVALID, "fps must be positive");
+        if (c->weights_host[m] < 0) return fail(PARC_ERR_INVALID, "motion weights must be >= 0");
+        e->h_weights[m] = (float)c->weights_host[m];
+        wsum = wsum + e->h_weights[m];
+    }
+    std::vector<int> frame_motion;
+    for (int m = 0; m < M; ++m) {
+        MotionMeta &mm = e->h_meta[m];
+        const int n = c->num_frames_host[m];
+        mm.start = (int)F; mm.nframes = n; mm.loop = c->loop_modes_host[m]; mm.fps = (float)c->fps_host[m];
+        mm.length = (float)(1.0 / (double)c->fps_host[m] * (double)(n - 1)); // motion_lib.py:305
+        const float *rp = c->root_pos_host + 3 * F;
+        mm.dx = rp[3 * (n - 1)] - rp[0]; mm.dy = rp[3 * (n - 1) + 1] - rp[1]; mm.dz = 0.f; // :307-308
+        e->h_weights[m] = e->h_weights[m] / wsum; // :372
+        for (int f = 0; f < n; ++f) frame_motion.push_back(m);
+        F += n;
+    }
+    if (F > (int64_t)1 << 30) return fail(PARC_ERR_INVALID, "too many frames");
+    void *olds[] = {e->d_records, e->d_meta, e->d_weights, e->d_fail, e->d_cdf};
+    for (void *p : olds) if (p) (void)hipFree(p);
+    e->d_records = nullptr; e->d_meta = nullptr; e->d_weights = nullptr; e->d_fail = nullptr; e->d_cdf = nullptr;
+    float *d_rp = nullptr, *d_rr = nullptr, *d_jr = nullptr, *d_ct = nullptr;
+    int *d_fm = nullptr;
+    HIPCHK(hipMalloc((void **)&e->d_records, sizeof(float4) * REC_F4 * F));
+    HIPCHK(hipMalloc((void **)&e->d_meta, sizeof(MotionMeta) * M));
+    HIPCHK(hipMalloc((void **)&e->d_weights, sizeof(float) * M));
+    HIPCHK(hipMalloc((void **)&e->d_fail, sizeof(float) * M));
+    HIPCHK(hipMalloc((void **)&e->d_cdf, sizeof(float) * M));
+    HIPCHK(hipMalloc((void **)&d_rp, sizeof(float) * 3 * F));
+    HIPCHK(hipMalloc((void **)&d_rr, sizeof(float) * 4 * F));
+    HIPCHK(hipMalloc((void **)&d_jr, sizeof(float) * 4 * J * F));
+    HIPCHK(hipMalloc((void **)&d_fm, sizeof(int) * F));
+    HIPCHK(hipMemcpy(e->d_meta, e->h_meta.data(), sizeof(MotionMeta) * M, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_weights, e->h_weights.data(), sizeof(float) * M, hipMemcpyHostToDevice));
+    std::vector<float> ones(M, 1.0f); // dm_env.py:87
+    HIPCHK(hipMemcpy(e->d_fail, ones.data(), sizeof(float) * M, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_rp, c->root_pos_host, sizeof(float) * 3 * F, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_rr, c->root_rot_host, sizeof(float) * 4 * F, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_jr, c->joint_rot_host, sizeof(float) * 4 * J * F, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_fm, frame_motion.data(), sizeof(int) * F, hipMemcpyHostToDevice));
+    if (c->contacts_host) {
+        HIPCHK(hipMalloc((void **)&d_ct, sizeof(float) * B * F));
+        HIPCHK(hipMemcpy(d_ct, c->contacts_host, sizeof(float) * B * F, hipMemcpyHostToDevice));
+    }
+    PrepParams pp;
+    pp.F = (int)F; pp.B = B; pp.J = J; pp.D = e->D; pp.root_pos = d_rp; pp.root_rot = d_rr; pp.joint_rot = d_jr; pp.contacts = d_ct;
+    pp.frame_motion = d_fm; pp.meta = e->d_meta; pp.tables = e->d_tab; pp.records = e->d_records;
+    hipLaunchKernelGGL(k_motion_prep, dim3((unsigned)((F + 127) / 128)), dim3(128), 0, 0, pp);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    (void)hipFree(d_rp); (void)hipFree(d_rr); (void)hipFree(d_jr); (void)hipFree(d_fm);
+    if (d_ct) (void)hipFree(d_ct);
+    e->M = M; e->F = F; e->have_motions = true;
+    e->sp.M = M; e->sp.records = e->d_records; e->sp.meta = e->d_meta;
+    return PARC_OK;
+}
+
+extern "C" int parc_env_load_terrain(ParcEnv *e, const float *hf, int32_t X, int32_t Y, float min_x, float min_y, float dx, float dy,
+                                     const float *motion_offsets, int32_t M, int32_t T) {
+    if (!e || !hf || !motion_offsets || X < 1 || Y < 1 || T < 1 || !(dx > 0.f) || !(dy > 0.f)) return fail(PARC_ERR_INVALID, "bad terrain");
+    if (!e->have_motions || M != e->M) return fail(PARC_ERR_STATE, "load_motions first; motion_offsets must have one row per motion");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    if (e->d_hf) (void)hipFree(e->d_hf);
+    if (e->d_motion_off) (void)hipFree(e->d_motion_off);
+    e->d_hf = nullptr; e->d_motion_off = nullptr;
+    HIPCHK(hipMalloc((void **)&e->d_hf, sizeof(float) * (size_t)X * Y));
+    HIPCHK(hipMalloc((void **)&e->d_motion_off, sizeof(float) * 2 * (size_t)M * T));
+    HIPCHK(hipMemcpy(e->d_hf, hf, sizeof(float) * (size_t)X * Y, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_motion_off, motion_offsets, sizeof(float) * 2 * (size_t)M * T, hipMemcpyHostToDevice));
+    StepParams &sp = e->sp;
+    sp.hf = e->d_hf; sp.X = X; sp.Y = Y; sp.min_x = min_x; sp.min_y = min_y; sp.dx = dx; sp.dy = dy; sp.T = T;
+    sp.motion_offsets = e->d_motion_off;
+    e->T = T;
+    // terrain tile radius: farthest ray sample in cells, +1 for the two independent roundings
+    std::vector<float> ray(2 * (size_t)e->R);
+    HIPCHK(hipMemcpy(ray.data(), e->d_ray, sizeof(float) * 2 * e->R, hipMemcpyDeviceToHost));
+    float rmax = 0.f;
+    for (int r = 0; r < e->R; ++r) rmax = fmaxf(rmax, sqrtf(ray[2 * r] * ray[2 * r] + ray[2 * r + 1] * ray[2 * r + 1]));
+    int tr = (int)ceilf(rmax / fminf(dx, dy) + 0.01f); // max |round(a+d)-round(a)| = ceil(|d|)
+    if (tr > 24) tr = 24; // larger fans fall back to direct gathers for the outer samples
+    sp.tile_r = tr;
+    const int obs_pad = (e->obs_dim + 3) & ~3;
+    e->lds_bytes = sizeof(float) * ((size_t)obs_pad + (size_t)(2 * tr + 1) * (2 * tr + 1));
+    e->have_terrain = true;
+    return PARC_OK;
+}
+
+extern "C" int parc_env_bind_buffers(ParcEnv *e, const ParcEnvBuffers *b) {
+    if (!e || !b) return fail(PARC_ERR_INVALID, "null argument");
+    const void *req[] = {b->char_root_pos, b->char_root_rot, b->char_root_vel, b->char_root_ang_vel, b->char_dof_pos, b->char_dof_vel,
+                         b->contact_forces, b->motion_ids, b->terrain_ids, b->time_offsets, b->timestep, b->obs, b->reward, b->done};
+    for (const void *p : req) if (!p) return fail(PARC_ERR_INVALID, "a required buffer is NULL");
+    if (!e->cfg.body_pos_from_fk && !b->char_body_pos) return fail(PARC_ERR_INVALID, "char_body_pos is required when body_pos_from_fk == 0");
+    if (((uintptr_t)b->obs & 15) != 0) return fail(PARC_ERR_INVALID, "obs must be 16-byte aligned");
+    if ((b->ref_root_rot && ((uintptr_t)b->ref_root_rot & 15)) || (b->ref_joint_rot && ((uintptr_t)b->ref_joint_rot & 15)) ||
+        ((uintptr_t)b->char_root_rot & 15))
+        return fail(PARC_ERR_INVALID, "quaternion buffers must be 16-byte aligned");
+    e->sp.buf = *b;
+    e->bound = true;
+    return PARC_OK;
+}
+
+static int check_ready(ParcEnv *e) {
+    if (!e) return fail(PARC_ERR_INVALID, "null env");
+    if (!e->bound || !e->have_motions || !e->have_terrain) return fail(PARC_ERR_STATE, "bind_buffers, load_motions and load_terrain must precede this call");
+    return PARC_OK;
+}
+
+static int launch_post(ParcEnv *e, int mode, const int64_t *ids, int count, hipStream_t st) {
+    if (count <= 0) return PARC_OK;
+    const int grid = count < e->grid_waves ? count : e->grid_waves;
+    if (mode == MODE_STEP) hipLaunchKernelGGL(k_env_post<MODE_STEP>, dim3(grid), dim3(64), e->lds_bytes, st, e->sp, ids, count);
+    else hipLaunchKernelGGL(k_env_post<MODE_OBS>, dim3(grid), dim3(64), e->lds_bytes, st, e->sp, ids, count);
+    HIPCHK(hipGetLastError());
+    return PARC_OK;
+}
+
+extern "C" int parc_env_step(ParcEnv *e, const float *action_dev, void *stream) {
+    int rc = check_ready(e);
+    if (rc) return rc;
+    (void)action_dev;
+    hipStream_t st = (hipStream_t)stream;
+    rc = launch_post(e, MODE_STEP, nullptr, e->N, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_curriculum, dim3(1), dim3(1024), 0, st, e->d_ema, e->sp.buf.motion_ids, e->d_done_list, e->d_done_count,
+                       e->d_fail, e->N, e->cfg.fail_rate_ema_weight);
+    HIPCHK(hipGetLastError());
+    return PARC_OK;
+}
+
+extern "C" int parc_env_compute_obs(ParcEnv *e, const int64_t *ids, int32_t k, void *stream) {
+    int rc = check_ready(e);
+    if (rc) return rc;
+    if (k == 0) return PARC_OK;
+    if (k > 0 && !ids) return fail(PARC_ERR_INVALID, "env_ids is NULL");
+    return launch_post(e, MODE_OBS, k < 0 ? nullptr : ids, k < 0 ? e->N : k, (hipStream_t)stream);
+}
+
+static ResetParams make_reset_params(ParcEnv *e) {
+    ResetParams rp;
+    rp.B = e->B; rp.J = e->J; rp.D = e->D; rp.T = e->T; rp.N = e->N;
+    rp.records = e->d_records; rp.meta = e->d_meta; rp.motion_offsets = e->d_motion_off; rp.env_offsets = e->d_env_off;
+    rp.tables = e->d_tab; rp.scratch_jr = e->d_scratch_jr; rp.buf = e->sp.buf;
+    return rp;
+}
+
+extern "C" int parc_env_reset_with(ParcEnv *e, const int64_t *ids, int32_t k, const int32_t *mids, const int32_t *tids, const float *t0,
+                                   const float *noise, void *stream) {
+    int rc = check_ready(e);
+    if (rc) return rc;
+    if (k == 0) return PARC_OK;
+    if (k > e->N) return fail(PARC_ERR_INVALID, "k > num_envs");
+    if (!mids || !tids || !t0 || !noise || (k > 0 && !ids)) return fail(PARC_ERR_INVALID, "null sample array");
+    const int n = k < 0 ? e->N : k;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_reset_with, dim3((n + 63) / 64), dim3(64), 0, st, make_reset_params(e), k < 0 ? nullptr : ids, n, mids, tids, t0, noise);
+    HIPCHK(hipGetLastError());
+    return launch_post(e, MODE_OBS, k < 0 ? nullptr : ids, n, st);
+}
+
+extern "C" int parc_env_reset(ParcEnv *e, const int64_t *ids, int32_t k, void *stream) {
+    int rc = check_ready(e);
+    if (rc) return rc;
+    if (k == 0) return PARC_OK;
+    if (k > e->N) return fail(PARC_ERR_INVALID, "k > num_envs");
+    if (k > 0 && !ids) return fail(PARC_ERR_INVALID, "env_ids is NULL");
+    const int n = k < 0 ? e->N : k;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_build_cdf, dim3(1), dim3(1024), 0, st, e->d_fail, e->d_weights, e->cfg.min_motion_weight, e->M, e->d_cdf);
+    hipLaunchKernelGGL(k_reset_sample, dim3((n + 127) / 128), dim3(128), 0, st, k < 0 ? nullptr : ids, n, e->M, e->T, e->d_cdf, e->d_meta,
+                       (unsigned long long)e->cfg.seed, e->reset_calls++, e->cfg.rand_reset, e->cfg.demo_mode,
+                       e->cfg.rand_root_pos_offset_scale, e->d_start_frac, e->d_tmp_mid, e->d_tmp_tid, e->d_tmp_t0, e->d_tmp_noise);
+    HIPCHK(hipGetLastError());
+    return parc_env_reset_with(e, k < 0 ? nullptr : ids, k, e->d_tmp_mid, e->d_tmp_tid, e->d_tmp_t0, e->d_tmp_noise, stream);
+}
+
+extern "C" int parc_env_get_fail_rates(ParcEnv *e, float *out, int32_t M) {
+    if (!e || !out || !e->have_motions || M != e->M) return fail(PARC_ERR_INVALID, "bad fail-rate query");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, e->d_fail, sizeof(float) * M, hipMemcpyDeviceToHost));
+    return PARC_OK;
+}
+
+extern "C" int parc_env_set_fail_rates(ParcEnv *e, const float *in, int32_t M) {
+    if (!e || !in || !e->have_motions || M != e->M) return fail(PARC_ERR_INVALID, "bad fail-rate update");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(e->d_fail, in, sizeof(float) * M, hipMemcpyHostToDevice));
+    return PARC_OK;
+}
+
+extern "C" int parc_env_get_motion_info(ParcEnv *e, float *lengths, float *weights, int32_t M) {
+    if (!e || !e->have_motions || M != e->M) return fail(PARC_ERR_INVALID, "bad motion-info query");
+    for (int m = 0; m < M; ++m) {
+        if (lengths) lengths[m] = e->h_meta[m].length;
+        if (weights) weights[m] = e->h_weights[m];
+    }
+    return PARC_OK;
+}
+
+extern "C" int parc_env_set_rand_reset(ParcEnv *e, int32_t rand_reset, int32_t demo_mode, float scale) {
+    if (!e) return fail(PARC_ERR_INVALID, "null env");
+    e->cfg.rand_reset = rand_reset; e->cfg.demo_mode = demo_mode; e->cfg.rand_root_pos_offset_scale = scale;
+    return PARC_OK;
+}
+
+extern "C" int parc_env_set_start_time_fraction(ParcEnv *e, const float *frac_dev) {
+    if (!e) return fail(PARC_ERR_INVALID, "null env");
+    e->d_start_frac = const_cast<float *>(frac_dev);
+    return PARC_OK;
+}
+
+extern "C" int parc_dof_to_rot(ParcEnv *e, const float *dof, float *jr, int32_t n, void *stream) {
+    if (!e || !dof || !jr || n < 0) return fail(PARC_ERR_INVALID, "bad argument");
+    if (n == 0) return PARC_OK;
+    hipLaunchKernelGGL(k_dof_to_rot, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, e->d_tab, dof, jr, n, e->B, e->D);
+    HIPCHK(hipGetLastError());
+    return PARC_OK;
+}
+
+extern "C" int parc_rot_to_dof(ParcEnv *e, const float *jr, float *dof, int32_t n, void *stream) {
+    if (!e || !dof || !jr || n < 0) return fail(PARC_ERR_INVALID, "bad argument");
+    if (n == 0) return PARC_OK;
+    hipLaunchKernelGGL(k_rot_to_dof, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, e->d_tab, jr, dof, n, e->B, e->D);
+    HIPCHK(hipGetLastError());
+    return PARC_OK;
+}
+
+extern "C" int parc_forward_kinematics(ParcEnv *e, const float *rp, const float *rr, const float *jr, float *bp, float *br, int32_t n,
+                                       void *stream) {
+    if (!e || !rp || !rr || !jr || !bp || n < 0) return fail(PARC_ERR_INVALID, "bad argument");
+    if (n == 0) return PARC_OK;
+    hipLaunchKernelGGL(k_fk, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, e->d_tab, rp, rr, jr, bp, br, n, e->B);
+    HIPCHK(hipGetLastError());
+    return PARC_OK;
+}
+
+extern "C" int parc_calc_motion_frame(ParcEnv *e, const int32_t *ids, const float *times, int32_t n, float *rp, float *rr, float *rv,
+                                      float *rav, float *jr, float *dv, float *ct, void *stream) {
+    if (!e || !e->have_motions) return fail(PARC_ERR_STATE, "load_motions first");
+    if (!ids || !times || !rp || !rr || !jr || n < 0) return fail(PARC_ERR_INVALID, "bad argument");
+    if (n == 0) return PARC_OK;
+    FrameOut F;
+    F.root_pos = rp; F.root_rot = rr; F.root_vel = rv; F.root_ang_vel = rav; F.joint_rot = jr; F.dof_vel = dv; F.contacts = ct;
+    hipLaunchKernelGGL(k_calc_motion_frame, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, e->d_records, e->d_meta, ids, times, n,
+                       e->B, e->J, e->D, F);
+    HIPCHK(hipGetLastError());
+    return PARC_OK;
+}
+
+extern "C" int parc_env_get_frame_vel_tables(ParcEnv *e, float *root_vel, float *root_ang_vel, float *dof_vel) {
+    if (!e || !e->have_motions) return fail(PARC_ERR_STATE, "load_motions first");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    std::vector<float> rec((size_t)e->F * 128);
+    HIPCHK(hipMemcpy(rec.data(), e->d_records, rec.size() * sizeof(float), hipMemcpyDeviceToHost));
+    for (int64_t f = 0; f < e->F; ++f) {
+        const float *v = rec.data() + (size_t)f * 128 + 4 * REC_Q_VEL;
+        if (root_vel) for (int c = 0; c < 3; ++c) root_vel[3 * f + c] = v[c];
+        if (root_ang_vel) for (int c = 0; c < 3; ++c) root_ang_vel[3 * f + c] = v[4 + c];
+        if (dof_vel) for (int d = 0; d < e->D; ++d) dof_vel[(size_t)f * e->D + d] = v[8 + d];
+    }
+    return PARC_OK;
+}
+
+extern "C" int parc_env_profile_step(ParcEnv *e, const float *action_dev, void *stream, int32_t iters, float *avg_ms, float *avg_post_ms) {
+    int rc = check_ready(e);
+    if (rc) return rc;
+    if (iters < 1) return fail(PARC_ERR_INVALID, "iters must be >= 1");
+    (void)action_dev;
+    hipStream_t st = (hipStream_t)stream;
+    double tot = 0.0, post = 0.0;
+    for (int i = 0; i < iters; ++i) {
+        HIPCHK(hipEventRecord(e->ev[0], st));
+        rc = launch_post(e, MODE_STEP, nullptr, e->N, st);
+        if (rc) return rc;
+        HIPCHK(hipEventRecord(e->ev[1], st));
+        hipLaunchKernelGGL(k_curriculum, dim3(1), dim3(1024), 0, st, e->d_ema, e->sp.buf.motion_ids, e->d_done_list, e->d_done_count,
+                           e->d_fail, e->N, e->cfg.fail_rate_ema_weight);
+        HIPCHK(hipEventRecord(e->ev[2], st));
+        HIPCHK(hipEventSynchronize(e->ev[2]));
+        float a = 0.f, b = 0.f;
+        HIPCHK(hipEventElapsedTime(&a, e->ev[0], e->ev[2]));
+        HIPCHK(hipEventElapsedTime(&b, e->ev[0], e->ev[1]));
+        tot += a; post += b;
+    }
+    if (avg_ms) *avg_ms = (float)(tot / iters);
+    if (avg_post_ms) *avg_post_ms = (float)(post / iters);
+    return PARC_OK;
+}

@@ -1,0 +1,351 @@
+"""``HipParkourEnv``: the reference's ``IGParkourEnv`` surface on top of ``libparc_env.so``.
+
+Same constructor signature, same ``reset(env_ids) / step(action)`` contract, same ``info`` keys and the
+private attributes the learner / recorder touch (``ig_parkour_env.py``, ``dm_env.py``,
+``ig_env.py``).  PyTorch owns every per-env tensor (so the agent can read them with zero copies); the library
+gets raw device pointers and enqueues its kernels on ``torch.cuda.current_stream()``.  There is no CPU
+path: constructing the env without a GPU or without the built library raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import time
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from parc_amd import lib as L
+from parc_amd.envs import base_env, scene as scene_mod
+from parc_amd.motion_lib import LoopMode
+
+
+def _device_index(device) -> int:
+    d = torch.device(device)
+    if d.type != "cuda":
+        raise RuntimeError(f"HipParkourEnv needs a ROCm GPU device (got {device!r}); there is no CPU fallback")
+    return 0 if d.index is None else d.index
+
+
+class _DMView:
+    """What the learner / recorder reach through ``env.get_dm_env()`` (``dm_env.py``)."""
+
+    def __init__(self, env):
+        self._env = env
+        self._ema_weight = 0.01
+
+    @property
+    def _motion_id_fail_rates(self):  # dm_ppo_agent.py:360-362 saves this tensor
+        return self._env.get_fail_rates()
+
+    @property
+    def _motion_ids(self):
+        return self._env._motion_ids
+
+    @property
+    def _terrains_per_motion(self):
+        return self._env._scene.grid.terrains_per_motion
+
+    def set_motion_start_time_fraction(self, val):  # dm_env.py:746-748
+        self._env.set_reset_motion_start_time_fraction(val)
+
+    def set_demo_mode(self, val=None):
+        return self._env.set_demo_mode(val)
+
+    def get_env_motion_length(self, env_ids):
+        return self._env._motion_lengths[self._env._motion_ids[env_ids].long()]
+
+    def get_env_motion_time(self, env_ids):
+        return self._env._time_buf[env_ids] + self._env._motion_time_offsets[env_ids]
+
+    def get_env_motion_name(self, env_id):
+        return self._env._motion_names[int(self._env._motion_ids[env_id].item())]
+
+    def get_extra_log_info(self):
+        return self._env._dm_extra_log_info()
+
+    def post_test_update(self):
+        return
+
+
+class HipParkourEnv(base_env.BaseEnv):
+    NAME = "hip_parkour"
+
+    def __init__(self, config, num_envs, device, visualize=False, env_id_base=0, total_envs=None, seed=0,
+                 mirror_ref_state=True, enable_dynamics=None):
+        super().__init__(visualize=False)
+        self._start_compute_time = time.time()
+        self._lib = L.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("HipParkourEnv: no ROCm GPU visible (torch.cuda.is_available() is False)")
+        self._config = config
+        self._device = device
+        self._num_envs = num_envs
+        self._num_dm_envs = num_envs
+        env_config = config["env"]
+        self._env_config = env_config
+        self._scene = sc = scene_mod.build_scene(config, num_envs, _device_index(device), env_id_base, total_envs,
+                                                 seed=seed, enable_dynamics=enable_dynamics)
+        self._kin_char_model = sc.char_model
+        self._episode_length = env_config["episode_length"]
+        self._control_freq = env_config["control_freq"]
+        self._timestep = 1.0 / self._control_freq
+        self._report_tracking_error = bool(env_config.get("report_tracking_error", False))
+        self._output_motion_dir = env_config.get("output_motion_dir", "output/_motions/recorded_motions/")
+        self._rand_reset = env_config.get("rand_reset", True)
+        self._demo_mode = env_config["demo_mode"]
+        self._rand_root_pos_offset_scale = env_config["rand_root_pos_offset_scale"]
+        self._never_done = env_config.get("never_done", False)
+        self._write_agent_states_flag = False
+        self._motion_names = [c.name for c in sc.clips]
+        self._key_body_ids = torch.tensor(sc.key_body_ids, dtype=torch.long, device=device)
+        self._tar_obs_steps = torch.tensor(env_config.get("tar_obs_steps", [1]), dtype=torch.int, device=device)
+
+        # ---- library handle + tables ----------------------------------------------------------------
+        self._handle = C.c_void_p()
+        L.check(self._lib.parc_env_create(C.byref(sc.cfg), C.byref(self._handle)))
+        p = sc.packed
+        mc = L.ParcMotionClips()
+        mc.num_motions = len(sc.clips)
+        mc.num_frames_host = L.np_i32p(p["num_frames"]); mc.fps_host = L.np_i32p(p["fps"])
+        mc.loop_modes_host = L.np_i32p(p["loop_modes"]); mc.weights_host = p["weights"].ctypes.data_as(L.f64p)
+        mc.root_pos_host = L.np_f32p(p["root_pos"]); mc.root_rot_host = L.np_f32p(p["root_rot"])
+        mc.joint_rot_host = L.np_f32p(p["joint_rot"]); mc.contacts_host = L.np_f32p(p["contacts"])
+        L.check(self._lib.parc_env_load_motions(self._handle, C.byref(mc)))
+        g = sc.grid
+        hf = np.ascontiguousarray(g.terrain.hf, np.float32)
+        mo = np.ascontiguousarray(g.motion_offsets, np.float32)
+        if mo.shape[0] != len(sc.clips):
+            raise ValueError("terrain cache does not match the motion list (delete terrain_save_path)")
+        L.check(self._lib.parc_env_load_terrain(self._handle, L.np_f32p(hf), hf.shape[0], hf.shape[1],
+                                                float(g.terrain.min_point[0]), float(g.terrain.min_point[1]),
+                                                float(g.terrain.dxdy[0]), float(g.terrain.dxdy[1]), L.np_f32p(mo),
+                                                mo.shape[0], mo.shape[1]))
+        M = len(sc.clips)
+        lengths = np.zeros(M, np.float32); weights = np.zeros(M, np.float32)
+        L.check(self._lib.parc_env_get_motion_info(self._handle, L.np_f32p(lengths), L.np_f32p(weights), M))
+        self._motion_lengths = torch.from_numpy(lengths).to(device)
+        self._motion_weights = torch.from_numpy(weights).to(device)
+        self._num_motions = M
+        self._obs_dim = self._lib.parc_env_obs_dim(self._handle)
+
+        self._build_buffers(mirror_ref_state)
+        low, high = sc.action_low, sc.action_high
+        self._action_space = base_env.Box(low=low, high=high)
+        self._action_bound_low = torch.tensor(low, device=device, dtype=torch.float32)
+        self._action_bound_high = torch.tensor(high, device=device, dtype=torch.float32)
+        if "fail_rates_path" in env_config["dm"]:  # dm_env.py:84-86
+            print("LOADING SAVED FAIL RATES")
+            fr = torch.load(env_config["dm"]["fail_rates_path"], weights_only=True).to(dtype=torch.float32).cpu().numpy()
+            self.set_fail_rates(fr)
+        self._dm_view = _DMView(self)
+        self._info = dict()
+        self.set_write_agent_states_flag(env_config.get("write_agent_states", False))
+        if self._demo_mode:
+            print("DEMO MODE ENABLED")
+
+    # ------------------------------------------------------------------------------------------------
+    def _build_buffers(self, mirror_ref_state):
+        n, dev = self._num_envs, self._device
+        cm = self._kin_char_model
+        B, D, J = cm.get_num_bodies(), cm.get_dof_size(), cm.get_num_bodies() - 1
+        R = self._scene.ray_points.shape[0]
+        z = lambda *s, dtype=torch.float32: torch.zeros(*s, dtype=dtype, device=dev)
+        self._char_root_pos = z(n, 3); self._char_root_rot = z(n, 4); self._char_root_rot[:, 3] = 1.0
+        self._char_root_vel = z(n, 3); self._char_root_ang_vel = z(n, 3)
+        self._char_dof_pos = z(n, D); self._char_dof_vel = z(n, D)
+        self._char_rigid_body_pos = z(n, B, 3)
+        self._char_contact_forces = z(n, B, 3)
+        self._motion_ids = z(n, dtype=torch.int32); self._motion_terrain_ids = z(n, dtype=torch.int32)
+        self._motion_time_offsets = z(n)
+        self._timestep_buf = z(n, dtype=torch.int32); self._time_buf = z(n)
+        self._ep_num_buf = z(n, dtype=torch.int64)
+        self._obs_buf = z(n, self._obs_dim); self._reward_buf = z(n); self._done_buf = z(n, dtype=torch.int32)
+        self._reward_terms = z(7, n)
+        self._tracking_error = z(n, 7) if self._report_tracking_error else None
+        self._motion_start_time_fraction = z(n)
+        ref = {}
+        if mirror_ref_state:
+            ref = dict(ref_root_pos=z(n, 3), ref_root_rot=z(n, 4), ref_root_vel=z(n, 3), ref_root_ang_vel=z(n, 3),
+                       ref_joint_rot=z(n, J, 4), ref_dof_pos=z(n, D), ref_dof_vel=z(n, D), ref_body_pos=z(n, B, 3),
+                       ref_contacts=z(n, B), ray_hfs=z(n, R))
+        for k, v in ref.items():
+            setattr(self, "_" + k, v)
+        self._mirror_ref_state = mirror_ref_state
+        b = L.ParcEnvBuffers()
+        names = dict(char_root_pos=self._char_root_pos, char_root_rot=self._char_root_rot, char_root_vel=self._char_root_vel,
+                     char_root_ang_vel=self._char_root_ang_vel, char_dof_pos=self._char_dof_pos,
+                     char_dof_vel=self._char_dof_vel, char_body_pos=self._char_rigid_body_pos,
+                     contact_forces=self._char_contact_forces, motion_ids=self._motion_ids,
+                     terrain_ids=self._motion_terrain_ids, time_offsets=self._motion_time_offsets,
+                     timestep=self._timestep_buf, time=self._time_buf, ep_num=self._ep_num_buf, obs=self._obs_buf,
+                     reward=self._reward_buf, done=self._done_buf, reward_terms=self._reward_terms,
+                     tracking_error=self._tracking_error, **ref)
+        ptr_t = {"f": L.f32p, "i": L.i32p, "l": L.i64p}
+        for name, kind in L.BUFFER_FIELDS:
+            t = names.get(name)
+            if t is not None:
+                assert t.is_contiguous()
+                setattr(b, name, C.cast(t.data_ptr(), ptr_t[kind]))
+        self._bufs = b
+        L.check(self._lib.parc_env_bind_buffers(self._handle, C.byref(b)))
+        L.check(self._lib.parc_env_set_start_time_fraction(self._handle, self._motion_start_time_fraction.data_ptr()))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_handle", None):
+                self._lib.parc_env_destroy(self._handle)
+                self._handle = None
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    # ---- BaseEnv contract ---------------------------------------------------------------------------
+    def get_num_envs(self):
+        return self._num_envs
+
+    def get_reward_bounds(self):  # ig_char_env.py:42
+        return (0.0, 1.0)
+
+    def get_obs_space(self):  # ig_env.py:86-96
+        return base_env.Box(low=-np.inf, high=np.inf, shape=[self._obs_dim], dtype=np.float32)
+
+    def reset(self, env_ids=None):
+        """ig_parkour_env.py:809-829.  ``None`` = all envs; a (possibly empty) LongTensor = that subset."""
+        if env_ids is None:
+            L.check(self._lib.parc_env_reset(self._handle, None, -1, self._stream()))
+        else:
+            env_ids = env_ids.to(device=self._device, dtype=torch.long).contiguous()
+            if env_ids.numel() > 0:
+                L.check(self._lib.parc_env_reset(self._handle, env_ids.data_ptr(), int(env_ids.numel()), self._stream()))
+        self._update_info()
+        return self._obs_buf, self._info
+
+    def reset_with(self, env_ids, motion_ids, terrain_ids, t0, xy_noise):
+        """Reset with the random draws injected (parity tests; ``parc_env_reset_with``)."""
+        dev = self._device
+        env_ids = env_ids.to(device=dev, dtype=torch.long).contiguous()
+        mids = motion_ids.to(device=dev, dtype=torch.int32).contiguous()
+        tids = terrain_ids.to(device=dev, dtype=torch.int32).contiguous()
+        t0 = t0.to(device=dev, dtype=torch.float32).contiguous()
+        nz = xy_noise.to(device=dev, dtype=torch.float32).contiguous()
+        L.check(self._lib.parc_env_reset_with(self._handle, env_ids.data_ptr(), int(env_ids.numel()), mids.data_ptr(),
+                                              tids.data_ptr(), t0.data_ptr(), nz.data_ptr(), self._stream()))
+        self._update_info()
+        return self._obs_buf, self._info
+
+    def step(self, action):
+        """ig_env.py:66-84: returns the persistent (obs, reward, done, info) tensors."""
+        a = None
+        if action is not None:
+            assert action.shape == (self._num_envs, self._char_dof_pos.shape[1]) and action.dtype == torch.float32
+            a = action.contiguous().data_ptr()
+        L.check(self._lib.parc_env_step(self._handle, a, self._stream()))
+        if self._never_done:
+            self._done_buf[:] = base_env.DoneFlags.NULL.value
+        self._update_info()
+        return self._obs_buf, self._reward_buf, self._done_buf, self._info
+
+    def _update_info(self):
+        """ig_parkour_env.py:1108-1116 + the reward dict of :1012-1044 (views, not clones: the agent copies them)."""
+        rt = self._reward_terms
+        self._info["rewards"] = {"pose_r": rt[0], "vel_r": rt[1], "root_pos_r": rt[2], "root_vel_r": rt[3],
+                                 "key_pos_r": rt[4], "contact_penalty": rt[5], "total_r": rt[6]}
+        self._info["timestep"] = self._timestep_buf
+        self._info["ep_num"] = self._ep_num_buf
+        self._info["compute_time"] = time.time() - self._start_compute_time
+        self._info["char_contact_forces"] = self._char_contact_forces
+        if self._report_tracking_error:
+            self._info["tracking_error"] = self._tracking_error
+
+    def _update_reward(self):
+        """The agent calls this once to size its return tracker (base_agent.py:229-234)."""
+        self._update_info()
+
+    def _compute_obs(self, env_ids=None, ret_obs_shapes=False):
+        if ret_obs_shapes:
+            print("OBS SHAPES")
+            for k, v in self._scene.obs_shapes.items():
+                print(k, v)
+            return self._scene.obs_shapes
+        if env_ids is None:
+            L.check(self._lib.parc_env_compute_obs(self._handle, None, -1, self._stream()))
+            return self._obs_buf
+        env_ids = env_ids.to(device=self._device, dtype=torch.long).contiguous()
+        L.check(self._lib.parc_env_compute_obs(self._handle, env_ids.data_ptr(), int(env_ids.numel()), self._stream()))
+        return self._obs_buf[env_ids]
+
+    # ---- dm env surface ------------------------------------------------------------------------------
+    def has_dm_envs(self):
+        return True
+
+    def get_dm_env(self):
+        return self._dm_view
+
+    def get_fail_rates(self):
+        out = np.zeros(self._num_motions, np.float32)
+        L.check(self._lib.parc_env_get_fail_rates(self._handle, L.np_f32p(out), self._num_motions))
+        return torch.from_numpy(out)
+
+    def set_fail_rates(self, fr):
+        fr = np.ascontiguousarray(np.asarray(fr, np.float32))
+        L.check(self._lib.parc_env_set_fail_rates(self._handle, L.np_f32p(fr), self._num_motions))
+
+    def _push_reset_mode(self):
+        L.check(self._lib.parc_env_set_rand_reset(self._handle, int(bool(self._rand_reset)), int(bool(self._demo_mode)),
+                                                  float(self._rand_root_pos_offset_scale)))
+
+    def set_rand_reset(self, val=None):
+        self._rand_reset = (not self._rand_reset) if val is None else val
+        self._push_reset_mode()
+        print("Setting rand reset to:", self._rand_reset)
+
+    def set_demo_mode(self, val=None):
+        self._demo_mode = (not self._demo_mode) if val is None else val
+        self._push_reset_mode()
+        return self._demo_mode
+
+    def set_rand_root_pos_offset_scale(self, val):
+        self._rand_root_pos_offset_scale = val
+        self._push_reset_mode()
+
+    def set_reset_motion_start_time_fraction(self, val):
+        self._motion_start_time_fraction[:] = val.to(self._device)
+
+    def set_output_motion_dir(self, path):
+        self._output_motion_dir = path
+
+    def set_write_agent_states_flag(self, val):
+        self._write_agent_states_flag = val
+
+    def is_writing_agent_states(self):
+        return self._write_agent_states_flag
+
+    def _dm_extra_log_info(self):
+        """dm_env.py:668-727 (per-motion fail rates + quantiles)."""
+        fr = self.get_fail_rates()
+        names = self._motion_names
+        top, ids = torch.sort(fr, descending=True)
+        q = torch.tensor(self._env_config["dm"]["fail_rate_quantiles"], dtype=torch.float32)
+        at_q = torch.quantile(top, q)
+        info = {"MOTION_FAIL_RATES": {names[i]: fr[i].item() * 100.0 for i in range(len(names))},
+                "Misc": {"top fail rate": top[0].item() * 100.0}}
+        for i in range(q.shape[0]):
+            info["Misc"]["Fail Rate at " + str(round(q[i].item() * 100.0)) + "% Quantile"] = at_q[i].item() * 100.0
+        return info
+
+    def get_extra_log_info(self):
+        return dict(self._dm_extra_log_info())
+
+    def post_test_update(self):
+        return
+
+    # ---- measurement ------------------------------------------------------------------------------------
+    def profile_step(self, iters=10, action=None):
+        a = None if action is None else action.contiguous().data_ptr()
+        tot = C.c_float(); post = C.c_float()
+        L.check(self._lib.parc_env_profile_step(self._handle, a, self._stream(), iters, C.byref(tot), C.byref(post)))
+        return tot.value, post.value

@@ -1,0 +1,284 @@
+"""-m gpu: the HIP library (through its C-ABI / the HipParkourEnv shim) against the golden vectors of the real
+reference and against the CPU oracle.  Tolerance: 1e-5 absolute-or-relative fp32 (BASELINE.json north_star);
+integer outputs (done flags, frame indices, timesteps) exact."""
+import numpy as np
+import pytest
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def close(a, b, tol=TOL, what=""):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = np.abs(a - b) / np.maximum(1.0, np.abs(b))
+    assert np.all(np.isfinite(err)) and err.max() <= tol, f"{what}: max err {err.max()} at {np.unravel_index(err.argmax(), err.shape)}"
+
+
+@pytest.fixture(scope="module")
+def genv(tmp_path_factory):
+    from gpu_helpers import golden_env
+    env, g = golden_env(tmp_path_factory.mktemp("scene"), body_pos_from_fk=False, tracking=True)
+    return env, g
+
+
+def _ops(env):
+    import ctypes as C
+    import torch
+    from parc_amd import lib as L
+
+    class Ops:
+        def __init__(self):
+            self.lib, self.h, self.dev = env._lib, env._handle, env._device
+            self.st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+        def t(self, a, dtype=None):
+            return torch.from_numpy(np.ascontiguousarray(a)).to(self.dev if dtype is None else self.dev, dtype=dtype)
+
+        def dof_to_rot(self, dof):
+            d = self.t(dof, torch.float32); out = torch.zeros(d.shape[0], 14, 4, device=self.dev)
+            L.check(self.lib.parc_dof_to_rot(self.h, d.data_ptr(), out.data_ptr(), d.shape[0], self.st)); return out.cpu().numpy()
+
+        def rot_to_dof(self, jr):
+            j = self.t(jr, torch.float32); out = torch.zeros(j.shape[0], 28, device=self.dev)
+            L.check(self.lib.parc_rot_to_dof(self.h, j.data_ptr(), out.data_ptr(), j.shape[0], self.st)); return out.cpu().numpy()
+
+        def fk(self, rp, rr, jr):
+            rp, rr, jr = self.t(rp, torch.float32), self.t(rr, torch.float32), self.t(jr, torch.float32)
+            n = rp.shape[0]
+            bp = torch.zeros(n, 15, 3, device=self.dev); br = torch.zeros(n, 15, 4, device=self.dev)
+            L.check(self.lib.parc_forward_kinematics(self.h, rp.data_ptr(), rr.data_ptr(), jr.data_ptr(), bp.data_ptr(), br.data_ptr(), n, self.st))
+            return bp.cpu().numpy(), br.cpu().numpy()
+
+        def motion_frame(self, ids, times):
+            i = self.t(ids, torch.int32); t = self.t(times, torch.float32); n = i.shape[0]
+            z = lambda *s: torch.zeros(*s, device=self.dev)
+            o = dict(root_pos=z(n, 3), root_rot=z(n, 4), root_vel=z(n, 3), root_ang_vel=z(n, 3), joint_rot=z(n, 14, 4), dof_vel=z(n, 28), contacts=z(n, 15))
+            L.check(self.lib.parc_calc_motion_frame(self.h, i.data_ptr(), t.data_ptr(), n, *[o[k].data_ptr() for k in
+                    ["root_pos", "root_rot", "root_vel", "root_ang_vel", "joint_rot", "dof_vel", "contacts"]], self.st))
+            return {k: v.cpu().numpy() for k, v in o.items()}
+    return Ops()
+
+
+def test_library_loaded_is_in_tree(genv):
+    from parc_amd import lib as L
+    assert L.LIB_PATH.endswith("parc_amd/libparc_env.so")
+    assert genv[0]._lib.parc_abi_version() == 1
+
+
+def test_kin_ops_vs_golden(genv):
+    env, _ = genv
+    ops = _ops(env)
+    g = golden("kin_ops")
+    close(ops.dof_to_rot(g["dof"]), g["joint_rot"], what="dof_to_rot")
+    close(ops.rot_to_dof(g["joint_rot"]), g["dof_back"], what="rot_to_dof")
+    close(ops.rot_to_dof(g["joint_rot_rand"]), g["dof_rand"], what="rot_to_dof rand")
+    bp, br = ops.fk(g["root_pos"], g["root_rot"], g["joint_rot"])
+    close(bp, g["body_pos"], what="fk pos"); close(br, g["body_rot"], what="fk rot")
+    bp, br = ops.fk(g["root_pos"], g["root_rot"], g["joint_rot_rand"])
+    close(bp, g["body_pos_rand"]); close(br, g["body_rot_rand"])
+
+
+def test_motion_lib_vs_golden(genv):
+    """calc_motion_frame + load-time velocity tables (same 4 clips / order as motion_lib.npz)."""
+    import ctypes as C
+    from parc_amd import lib as L
+    env, _ = genv
+    ops = _ops(env)
+    g = golden("motion_lib")
+    F = g["frame_root_pos"].shape[0]
+    rv = np.zeros((F, 3), np.float32); rav = np.zeros((F, 3), np.float32); dv = np.zeros((F, 28), np.float32)
+    L.check(env._lib.parc_env_get_frame_vel_tables(env._handle, L.np_f32p(rv), L.np_f32p(rav), L.np_f32p(dv)))
+    close(rv, g["frame_root_vel"], tol=1e-6, what="frame_root_vel")
+    close(rav, g["frame_root_ang_vel"], tol=3e-5, what="frame_root_ang_vel")
+    close(dv, g["frame_dof_vel"], tol=3e-5, what="frame_dof_vel")
+    close(env._motion_lengths.cpu().numpy(), g["motion_lengths"], tol=0)
+    close(env._motion_weights.cpu().numpy(), g["motion_weights"], tol=1e-7)
+    o = ops.motion_frame(g["q_ids"], g["q_times"])
+    for k in ["root_pos", "root_rot", "joint_rot", "contacts"]:
+        close(o[k], g[k], what=k)
+    for k in ["root_vel", "root_ang_vel", "dof_vel"]:
+        close(o[k], g[k], tol=3e-5, what=k)
+
+
+def test_known_answers_sfu(genv):
+    """SURVEY §8(c) known answers (motion 0 = sfu in the golden scene)."""
+    env, _ = genv
+    ops = _ops(env)
+    o = ops.motion_frame(np.array([0, 0]), np.array([0.10, 0.21], np.float32))
+    close(o["root_pos"][0], [10.8036976, 1.8566505, 0.7566922], tol=1e-6)
+    close(o["root_rot"][1], [-0.0113259, -0.0050410, 0.6899159, 0.7237490], tol=1e-6)
+    bp, _ = ops.fk(o["root_pos"], o["root_rot"], o["joint_rot"])
+    close(bp[0, 11], [10.9086103, 1.8863832, 0.1450104], tol=1e-6)
+    close(bp[1, 8], [10.5470676, 2.4380567, 0.7927424], tol=1e-6)
+    dof = ops.rot_to_dof(o["joint_rot"])
+    close(dof[1, 0:6], [-0.0387498, 0.4994673, -0.0135002, 0.0099086, 0.1129964, 0.0633409], tol=1e-6)
+
+
+def _check_step_outputs(env, g, p, oracle_state=None):
+    from gpu_helpers import to_np
+    assert np.array_equal(to_np(env._timestep_buf), g[p + "timestep"])
+    close(to_np(env._time_buf), g[p + "time"], tol=0, what="time")
+    for k in ["ref_root_pos", "ref_root_rot", "ref_joint_rot", "ref_body_pos", "ref_contacts", "ref_dof_pos"]:
+        close(to_np(getattr(env, "_" + k)), g[p + k], what=k)
+    for k in ["ref_root_vel", "ref_root_ang_vel", "ref_dof_vel"]:
+        close(to_np(getattr(env, "_" + k)), g[p + k], tol=3e-5, what=k)
+    ray = to_np(env._ray_hfs)
+    ray_bad = np.abs(ray - g[p + "ray_hfs"]) > TOL  # a 1-ulp sin/cos difference can move a sample across a cell edge
+    assert ray_bad.mean() < 2e-4, ray_bad.sum()
+    obs = to_np(env._obs_buf)
+    err = np.abs(obs - g[p + "obs"]); err[:, 871:][ray_bad] = 0
+    assert err.max() <= TOL, (err.max(), np.unravel_index(err.argmax(), err.shape))
+    assert np.array_equal(obs[:, 871:], ray)
+    close(to_np(env._reward_buf), g[p + "reward"], what="reward")
+    names = ["pose_r", "vel_r", "root_pos_r", "root_vel_r", "key_pos_r", "contact_penalty", "total_r"]
+    rt = to_np(env._reward_terms)
+    for i, nm in enumerate(names):
+        close(rt[i], g[p + "r_" + nm], what=nm)
+    close(to_np(env._tracking_error), g[p + "tracking_error"], what="tracking_error")
+    assert np.array_equal(to_np(env._done_buf), g[p + "done"])
+    close(env.get_fail_rates().numpy(), g[p + "fail_rates"], tol=0, what="fail_rates")
+
+
+def test_env_step_vs_reference_golden(genv):
+    """Three control steps on injected state vs the reference's own IGEnv._post_physics_step outputs."""
+    from gpu_helpers import inject
+    env, g = genv
+    for s in range(3):
+        inject(env, g, f"s{s}_in_")
+        obs, rew, done, info = env.step(None)
+        assert obs is env._obs_buf and rew is env._reward_buf and done is env._done_buf
+        assert set(info["rewards"].keys()) == {"pose_r", "vel_r", "root_pos_r", "root_vel_r", "key_pos_r", "contact_penalty", "total_r"}
+        _check_step_outputs(env, g, f"s{s}_out_")
+
+
+def test_env_reset_vs_reference_golden(genv):
+    import torch
+    from gpu_helpers import to_np
+    env, g = genv
+    n = env.get_num_envs()
+    ep0 = to_np(env._ep_num_buf).copy()
+    env.reset_with(torch.arange(n), torch.from_numpy(g["reset_motion_ids"]), torch.from_numpy(g["reset_terrain_ids"]),
+                   torch.from_numpy(g["reset_time_offsets"]), torch.from_numpy(g["reset_xy_noise"]))
+    for k in ["char_root_rot", "char_root_vel", "char_root_ang_vel", "char_dof_pos", "char_dof_vel"]:
+        close(to_np(getattr(env, "_" + k)), g["reset_" + k], tol=3e-5, what=k)
+    close(to_np(env._char_root_pos), g["reset_char_root_pos"])
+    close(to_np(env._ref_root_pos), g["reset_ref_root_pos"])
+    close(to_np(env._ref_contacts), g["reset_ref_contacts"])
+    assert np.array_equal(to_np(env._timestep_buf), np.zeros(n, np.int32)) and np.all(to_np(env._done_buf) == 0)
+    assert np.array_equal(to_np(env._ep_num_buf), ep0 + 1)
+    ray_bad = np.abs(to_np(env._ray_hfs) - g["reset_ray_hfs"]) > TOL
+    assert ray_bad.mean() < 2e-4
+    err = np.abs(to_np(env._obs_buf) - g["reset_obs"]); err[:, 871:][ray_bad] = 0
+    assert err.max() <= TOL, err.max()
+    # subset reset: untouched rows keep their observation
+    before = to_np(env._obs_buf).copy()
+    env.reset(torch.tensor([3, 17], device="cuda:0"))
+    after = to_np(env._obs_buf)
+    keep = np.ones(n, bool); keep[[3, 17]] = False
+    assert np.array_equal(before[keep], after[keep])
+    env.reset(torch.zeros(0, dtype=torch.long))  # empty id list is a no-op (base_agent.py:366-369)
+    assert np.array_equal(after, to_np(env._obs_buf))
+
+
+@pytest.mark.parametrize("n", [4096, 16384])
+def test_env_step_vs_oracle_large(tmp_path, oracle, orc_char, n):
+    """Same seeded state through the HIP step and the CPU oracle at cfg-2/cfg-3 env counts (from-FK bodies)."""
+    import torch
+    from gpu_helpers import default_config, write_motion_yaml, to_np
+    from helpers import CLIPS4, load_clips, make_orc_mlib, default_cfg
+    from parc_amd.envs.hip_parkour_env import HipParkourEnv
+    cfg = default_config()
+    w = [1.0, 1.5, 2.0, 2.5]
+    cfg["env"]["dm"]["motion_file"] = write_motion_yaml(tmp_path, CLIPS4, w)
+    env = HipParkourEnv(cfg, n, "cuda:0", False, seed=7)
+    env.reset()
+    rng = np.random.default_rng(0)
+    steps = 3
+    sc = env._scene
+    clips = load_clips(CLIPS4)
+    lib = make_orc_mlib(oracle, orc_char, clips, w)
+    ocfg = default_cfg(oracle, n, sc.ray_points, sc.env_offsets, sc.grid.motion_offsets)
+    ter = oracle.make_terrain(sc.grid.terrain.hf, sc.grid.terrain.min_point, sc.grid.terrain.dxdy)
+    st = oracle.make_state(n, M=4, tracking_error=False)
+    for s in range(steps):
+        # perturb the character state like a tracking controller would leave it
+        env._char_root_pos += 0.02 * torch.randn_like(env._char_root_pos)
+        env._char_dof_pos += 0.05 * torch.randn_like(env._char_dof_pos)
+        env._char_dof_vel += 0.2 * torch.randn_like(env._char_dof_vel)
+        env._char_root_rot[:] = torch.nn.functional.normalize(env._char_root_rot + 0.02 * torch.randn_like(env._char_root_rot), dim=-1)
+        f = torch.randn_like(env._char_contact_forces) * (torch.rand_like(env._char_contact_forces[..., :1]) < 0.3)
+        env._char_contact_forces[:] = f
+        for k_o, k_e in [("char_root_pos", "_char_root_pos"), ("char_root_rot", "_char_root_rot"), ("char_root_vel", "_char_root_vel"),
+                         ("char_root_ang_vel", "_char_root_ang_vel"), ("char_dof_pos", "_char_dof_pos"), ("char_dof_vel", "_char_dof_vel"),
+                         ("contact_forces", "_char_contact_forces"), ("time_offsets", "_motion_time_offsets"), ("timestep_buf", "_timestep_buf")]:
+            st[k_o][...] = to_np(getattr(env, k_e))
+        st["motion_ids"][...] = to_np(env._motion_ids); st["terrain_ids"][...] = to_np(env._motion_terrain_ids)
+        st["fail_rates"][...] = env.get_fail_rates().numpy()
+        jr = oracle.dof_to_rot(orc_char, st["char_dof_pos"])
+        st["char_body_pos"][...] = oracle.forward_kinematics(orc_char, st["char_root_pos"], st["char_root_rot"], jr)[0]
+        env.step(None)
+        oracle.env_post_physics_step(orc_char, lib, ter, ocfg, st)
+        oracle.env_update_curriculum(lib, ocfg, st)
+        obs = to_np(env._obs_buf)
+        ray_bad = np.abs(obs[:, 871:] - st["obs"][:, 871:]) > TOL
+        assert ray_bad.mean() < 2e-4
+        err = np.abs(obs - st["obs"]); err[:, 871:][ray_bad] = 0
+        # With 64 envs per row the env-local coordinates reach ~300 m, where one fp32 ulp is 3e-5: the
+        # reference quantises positions there exactly like we do, but a 1-ulp difference in a rotated offset
+        # can flip the rounding of `root + offset`.  Bound: 1e-5 + 2 ulp(|p|max) per row.
+        pmax = np.abs(st["char_root_pos"]).max(axis=1) + 8.0
+        row_tol = TOL + 2.4e-7 * pmax
+        assert (err.max(axis=1) <= row_tol).all(), (s, err.max(), np.unravel_index(err.argmax(), err.shape))
+        near = pmax < 48.0  # rows whose coordinates stay below 48 m meet the plain 1e-5 bar
+        assert near.sum() > 0 and err[near].max() <= TOL, err[near].max()
+        rerr = np.abs(to_np(env._reward_buf) - st["reward"])
+        assert (rerr <= row_tol).all() and rerr[near].max() <= TOL, rerr.max()
+        done_h = to_np(env._done_buf)
+        mism = done_h != st["done"]
+        assert mism.mean() < 1e-4, mism.sum()  # threshold compares on values that differ by 1 ulp
+        if not mism.any():
+            close(env.get_fail_rates().numpy(), st["fail_rates"], tol=1e-6, what="fail_rates")
+        done_ids = torch.nonzero(env._done_buf != 0).flatten()
+        env.reset(done_ids)
+    assert np.isfinite(to_np(env._obs_buf)).all()
+
+
+def test_full_size_properties(tmp_path):
+    """65 536 envs (BASELINE metric size): size-independent properties instead of a full oracle run."""
+    import torch
+    from gpu_helpers import default_config, write_motion_yaml, to_np
+    from helpers import CLIPS4
+    from parc_amd.envs.hip_parkour_env import HipParkourEnv
+    n = 65536
+    cfg = default_config()
+    cfg["env"]["dm"]["motion_file"] = write_motion_yaml(tmp_path, CLIPS4, [1, 1, 1, 1])
+    env = HipParkourEnv(cfg, n, "cuda:0", False, seed=3)
+    obs, info = env.reset()
+    assert obs.shape == (n, 1312) and torch.isfinite(obs).all()
+    # right after reset the character IS the reference pose (+xy noise): pose/vel/key rewards are exactly 1
+    _, rew, done, info = env.step(None)
+    torch.cuda.synchronize()
+    assert torch.isfinite(obs).all() and torch.isfinite(rew).all()
+    # determinism: same seed -> bit-identical observation stream
+    env2 = HipParkourEnv(cfg, n, "cuda:0", False, seed=3)
+    obs2, _ = env2.reset()
+    env2.step(None)
+    assert torch.equal(obs, obs2) and torch.equal(rew, env2._reward_buf)
+    # contact flags / clamp ranges
+    hf = obs[:, 871:]
+    assert hf.min() >= -3.0 and hf.max() <= 3.0
+    cc = obs[:, 856:871]
+    assert ((cc == 0) | (cc == 1)).all()
+    assert set(torch.unique(done).tolist()) <= {0, 1, 3}
+    # tan-norm pairs are orthonormal
+    tn = obs[:, 0:6]
+    assert torch.allclose((tn[:, :3] * tn[:, 3:]).sum(-1), torch.zeros(n, device=obs.device), atol=1e-5)
+    assert torch.allclose(tn[:, :3].norm(dim=-1), torch.ones(n, device=obs.device), atol=1e-4)
+    # sampled motions follow the weights (uniform here) within 5 sigma
+    counts = torch.bincount(env._motion_ids.long(), minlength=4).float().cpu().numpy()
+    assert np.all(np.abs(counts - n / 4) < 5 * np.sqrt(n * 0.25 * 0.75))
+    # time offsets inside the clip
+    assert (env._motion_time_offsets >= 0).all() and (env._motion_time_offsets <= env._motion_lengths[env._motion_ids.long()]).all()
