@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env-steps/s of the motion-tracking env step at 65 536 envs per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is what the PPO rollout does to the env per control step (base_agent.py:348-370): ``env.step(action)``
+followed by the reset of the envs that finished.  Envs shard across ranks with no data-path collective
+(``scaling: weak``: every GPU owns ``--envs`` envs; offsets follow the global env index).  Rank 0 prints ONE JSON line.
+
+The JSON carries ``roofline`` (algorithmic HBM bytes of the step kernel / its hipEvent-measured duration, against
+the 8 TB/s HBM peak) and, at N=1, ``cpu_baseline`` (the CPU oracle — a scalar C port of the reference step, first
+pinned against the reference's golden vectors — timed on this host's cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+# SURVEY.md §8(d) / BASELINE.md §4: algorithmic HBM bytes per env-step
+BYTES_KINEMATIC = 5772   # read state 276 + contact forces 180 + bookkeeping 24; write obs 5248 + reward/done/terms 44
+BYTES_DYNAMICS = 6340    # + action 112, state write-back 276, contact-force write 180
+HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
+    ap.add_argument("--config", default=os.path.join(REPO, "data/configs/tracker_config/dm_env_default.yaml"))
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dynamics", type=int, default=-1, help="-1: whatever the build supports; 0/1 force")
+    return ap.parse_args()
+
+
+def cpu_baseline(env, seconds):
+    """Time the CPU oracle (oracle/parc_oracle.c) on the same scene/state, all host cores, bounded sample."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from oracle.binding import Oracle
+    import helpers
+    from conftest import golden
+    oracle = Oracle()
+    cg = golden("char_model")
+    oc = oracle.make_char(cg["parent"], cg["local_translation"], cg["local_rotation"], cg["joint_type"], cg["joint_axis"],
+                          cg["dof_idx"], int(cg["dof_size"]))
+    sc = env._scene
+    n = env.get_num_envs()
+    clips = helpers.load_clips([c.name for c in sc.clips])
+    lib = oracle.mlib_create(oc, clips, [c.weight for c in sc.clips])
+    ocfg = helpers.default_cfg(oracle, n, sc.ray_points, sc.env_offsets, sc.grid.motion_offsets)
+    ter = oracle.make_terrain(sc.grid.terrain.hf, sc.grid.terrain.min_point, sc.grid.terrain.dxdy)
+    st = oracle.make_state(n, M=len(clips), tracking_error=False)
+    for ko, ke in [("char_root_pos", "_char_root_pos"), ("char_root_rot", "_char_root_rot"), ("char_root_vel", "_char_root_vel"),
+                   ("char_root_ang_vel", "_char_root_ang_vel"), ("char_dof_pos", "_char_dof_pos"), ("char_dof_vel", "_char_dof_vel"),
+                   ("contact_forces", "_char_contact_forces"), ("time_offsets", "_motion_time_offsets"),
+                   ("char_body_pos", "_char_rigid_body_pos")]:
+        st[ko][...] = getattr(env, ke).cpu().numpy()
+    st["motion_ids"][...] = env._motion_ids.cpu().numpy(); st["terrain_ids"][...] = env._motion_terrain_ids.cpu().numpy()
+    cores = max(1, min(os.cpu_count() or 1, 64))
+    bounds = np.linspace(0, n, cores + 1).astype(int)
+
+    def run_step():
+        th = [threading.Thread(target=oracle.env_post_physics_step, args=(oc, lib, ter, ocfg, st, int(bounds[i]), int(bounds[i + 1])))
+              for i in range(cores)]
+        for t in th: t.start()
+        for t in th: t.join()
+        oracle.env_update_curriculum(lib, ocfg, st)
+
+    run_step()  # warm-up
+    st["timestep_buf"][:] = 0
+    t0 = time.time(); steps = 0
+    while steps < 3 or (time.time() - t0 < seconds and steps < 10000):
+        st["timestep_buf"][:] = steps % 8  # stay inside the clips
+        run_step(); steps += 1
+    dt = time.time() - t0
+    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} kinematic steps x {n} envs, C oracle (scalar, -O2, one thread per core), same scene and state"}
+
+
+def main():
+    a = parse()
+    import torch
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = f"cuda:{local}"
+    from parc_amd.envs.hip_parkour_env import HipParkourEnv
+    from parc_amd.util import path_loader
+    cfg = path_loader.load_config(a.config)
+    dyn = None if a.dynamics < 0 else bool(a.dynamics)
+    sys.stdout = sys.stderr if rank == 0 else open(os.devnull, "w")  # the only stdout line is the JSON below
+    env = HipParkourEnv(cfg, a.envs, dev, False, env_id_base=rank * a.envs, total_envs=world * a.envs, seed=1234 + rank,
+                        mirror_ref_state=False, enable_dynamics=dyn)
+    dynamics_on = bool(env._scene.cfg.enable_dynamics)
+    D = env._char_dof_pos.shape[1]
+    # untrained-policy actions (SURVEY §8(d) cfg 3): action-normalizer mean + N(0, 0.05^2) * std
+    lo, hi = env._action_bound_low, env._action_bound_high
+    mean, std = 0.5 * (hi + lo), 0.5 * (hi - lo)
+    actions = [mean + 0.05 * std * torch.randn(a.envs, D, device=dev) for _ in range(4)]
+    env.reset()
+
+    def one_step(i):
+        env.step(actions[i & 3])
+        env.reset_done()
+
+    for i in range(a.warmup):
+        one_step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        one_step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # dominant kernel, measured live with hipEvents on the launch stream
+    tot_ms, post_ms = env.profile_step(iters=20, action=actions[0])
+    bytes_per = BYTES_DYNAMICS if dynamics_on else BYTES_KINEMATIC
+    achieved = bytes_per * a.envs / (post_ms * 1e-3) / 1e9
+    out = {
+        "metric": "env-steps/s", "value": a.envs * world * a.steps / dt, "unit": "env-steps/s", "n_gpus": world,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": ("full step (dynamics + obs/reward/done)" if dynamics_on else "kinematic step (ref slerp + FK + 441-ray hf + obs + reward + done), no physics")
+                               + f", {a.envs} envs per GPU, 5 bundled clips on a square blocky grid, reset of finished envs included",
+                   "envs_per_gpu": a.envs, "total_envs": a.envs * world, "dynamics": dynamics_on, "parallelism": f"env-shard x{world}"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "kernel": "k_env_post<MODE_STEP>", "kernel_ms": post_ms,
+                     "algorithmic_bytes_per_env_step": bytes_per},
+    }
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(env, a.cpu_seconds)
+    if rank == 0:
+        sys.stdout = sys.__stdout__
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -195,6 +195,9 @@ int parc_env_reset(ParcEnv *env, const int64_t *env_ids_dev, int32_t k, void *st
 /* Same with the random draws injected (parity tests): all arrays device, length k. */
 int parc_env_reset_with(ParcEnv *env, const int64_t *env_ids_dev, int32_t k, const int32_t *motion_ids_dev,
                         const int32_t *terrain_ids_dev, const float *t0_dev, const float *xy_noise_dev, void *stream);
+/* BaseAgent._reset_done_envs (base_agent.py:366-370) fused on the device: resets every env whose done flag was
+ * raised by the last parc_env_step, using the step's own compacted done list (no nonzero(), no host sync). */
+int parc_env_reset_done(ParcEnv *env, void *stream);
 /* _update_observations(env_ids) (ig_env.py:396-403): rays + obs rows only. k < 0 = all. */
 int parc_env_compute_obs(ParcEnv *env, const int64_t *env_ids_dev, int32_t k, void *stream);
 

@@ -72,7 +72,7 @@ struct StepParams {
     const float4 *records; const MotionMeta *meta; const float *motion_offsets; const float *env_offsets;
     const float *ray_points; const DevTables *tables;
     // curriculum hand-off
-    unsigned char *ema_code; int *done_list; int *done_count;
+    unsigned char *ema_code; int *chunk_count; int *motion_done_count;
     ParcEnvBuffers buf;
 };
 
@@ -129,7 +129,8 @@ __device__ __forceinline__ int cell_index(float p, float mn, float d) {
 #define MODE_OBS 1
 
 template <int MODE>
-__global__ __launch_bounds__(64) void k_env_post(const StepParams P, const int64_t *__restrict__ env_ids, int count) {
+__global__ __launch_bounds__(64) void k_env_post(const StepParams P, const int64_t *__restrict__ env_ids,
+                                                 const int *__restrict__ env_ids32, const int *__restrict__ count_dev, int count) {
     extern __shared__ __align__(16) float s_dyn[]; // [obs_dim rounded to 4][tile]
     __shared__ DevTables s_tab;
     __shared__ float4 s_q[8][16];   // row r: quats 0..14 (0 = root), slot 15 = root position
@@ -154,9 +155,10 @@ __global__ __launch_bounds__(64) void k_env_post(const StepParams P, const int64
     __syncthreads();
 
     const int B = P.B, D = P.D, S = P.S, K = P.K;
+    if (count_dev) count = *count_dev; // device-side list (reset_done): no host round trip
 
     for (int it = blockIdx.x; it < count; it += gridDim.x) {
-        int e = env_ids ? (int)env_ids[it] : it;
+        int e = env_ids ? (int)env_ids[it] : (env_ids32 ? env_ids32[it] : it);
         e = __builtin_amdgcn_readfirstlane(e);
 
         // ---- bookkeeping + time (ig_env.py:391-394, dm_env.py:547-552) -------------------------
@@ -480,7 +482,7 @@ __global__ __launch_bounds__(64) void k_env_post(const StepParams P, const int64
                 if (motion_end) done = PARC_DONE_FAIL;
                 P.buf.done[e] = done;
                 P.ema_code[e] = code;
-                if (code) { const int slot = atomicAdd(P.done_count, 1); P.done_list[slot] = e; }
+                if (code) { atomicAdd(P.chunk_count + (e >> 10), 1); atomicAdd(P.motion_done_count + mid, 1); }
                 P.buf.timestep[e] = ts;
                 if (P.buf.time) P.buf.time[e] = time;
             }
@@ -549,51 +551,65 @@ __global__ __launch_bounds__(64) void k_env_post(const StepParams P, const int64
 }
 
 // ------------------------------------------------------------------------------------------------
-// curriculum: sequential fail-rate EMA in env order (dm_env.py:646-660), exact op order per motion
+// curriculum: sequential fail-rate EMA in env order (dm_env.py:646-660), exact op order per motion.
+//   k_done_scatter: ordered (stable) compaction of the finished envs, one block per 1024 envs; the per-chunk
+//                   totals were counted by the step kernel, so a block's base offset is a 128-term sum.
+//   k_fail_rate_ema: one wave per motion walks the env-ordered list 64 entries at a time and applies
+//                   f <- f*(1-w)+w (FAIL) / f <- f*(1-w) (TIME, SUCC, motion end) in that order.
+// The compacted list doubles as the env-id list of parc_env_reset_done (no nonzero(), no host sync).
 // ------------------------------------------------------------------------------------------------
-#define CUR_FAST_MAX 2048
-__global__ __launch_bounds__(1024) void k_curriculum(const unsigned char *__restrict__ ema_code, const int *__restrict__ motion_ids,
-                                                     int *done_list, int *done_count, float *fail_rates, int N, float w) {
-    __shared__ unsigned long long s_key[CUR_FAST_MAX];
-    __shared__ unsigned long long s_sorted[CUR_FAST_MAX];
-    const int k = *done_count;
+__global__ __launch_bounds__(1024) void k_done_scatter(const unsigned char *__restrict__ ema_code, const int *__restrict__ motion_ids,
+                                                       const int *__restrict__ chunk_count, int nchunks, int N, int *done_list,
+                                                       int *done_key, int *reset_count) {
+    __shared__ int s_base, s_wave[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.x;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    if (tid < b && tid < nchunks) atomicAdd(&s_base, chunk_count[tid]);
+    const int e = b * 1024 + tid;
+    const unsigned char code = e < N ? ema_code[e] : 0;
+    const unsigned long long mask = __ballot(code != 0);
+    const int prefix = __popcll(mask & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wave[wv] = __popcll(mask);
+    __syncthreads();
+    int woff = 0, total = 0;
+    for (int i = 0; i < 16; ++i) { const int c = s_wave[i]; if (i < wv) woff += c; total += c; }
+    if (code) {
+        const int pos = s_base + woff + prefix;
+        done_list[pos] = e;
+        done_key[pos] = (motion_ids[e] << 1) | (code == 1 ? 1 : 0);
+    }
+    if (b == (int)gridDim.x - 1 && tid == 0) *reset_count = s_base + total;
+}
+
+__global__ __launch_bounds__(256) void k_fail_rate_ema(const int *__restrict__ done_key, const int *__restrict__ reset_count,
+                                                       int *motion_done_count, int *chunk_count, int nchunks, float *fail_rates,
+                                                       int M, float w) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < nchunks; i += 256) chunk_count[i] = 0; // consumed by k_done_scatter
+    if (m >= M) return;
+    const int c = motion_done_count[m];
+    if (c == 0) return;
+    const int k = *reset_count;
     const float keep = (float)(1.0 - (double)w);
-    if (k == 0) return;
-    if (k <= CUR_FAST_MAX) {
-        for (int i = threadIdx.x; i < k; i += blockDim.x) {
-            const int e = done_list[i];
-            s_key[i] = ((unsigned long long)(unsigned)motion_ids[e] << 32) | ((unsigned long long)(unsigned)e << 1) |
-                       (unsigned long long)(ema_code[e] == 1 ? 1 : 0);
-        }
-        __syncthreads();
-        for (int i = threadIdx.x; i < k; i += blockDim.x) { // rank sort: keys are unique (env id inside)
-            const unsigned long long key = s_key[i];
-            int rank = 0;
-            for (int j = 0; j < k; ++j) rank += (s_key[j] < key) ? 1 : 0;
-            s_sorted[rank] = key;
-        }
-        __syncthreads();
-        for (int i = threadIdx.x; i < k; i += blockDim.x) {
-            const unsigned m = (unsigned)(s_sorted[i] >> 32);
-            if (i == 0 || (unsigned)(s_sorted[i - 1] >> 32) != m) { // segment head: apply the chain in env order
-                float f = fail_rates[m];
-                for (int j = i; j < k && (unsigned)(s_sorted[j] >> 32) == m; ++j)
-                    f = (s_sorted[j] & 1ull) ? (f * keep + w) : (f * keep);
-                fail_rates[m] = f;
-            }
-        }
-    } else if (threadIdx.x == 0) { // rare (synchronised time-outs): the reference's own sequential loop
-        for (int e = 0; e < N; ++e) {
-            const unsigned char c = ema_code[e];
-            if (c) {
-                const int m = motion_ids[e];
-                const float f = fail_rates[m];
-                fail_rates[m] = c == 1 ? (f * keep + w) : (f * keep);
-            }
+    float f = fail_rates[m];
+    int seen = 0;
+    for (int base = 0; base < k && seen < c; base += 64) {
+        const int i = base + lane;
+        const int v = i < k ? done_key[i] : -2;
+        const bool match = (v >> 1) == m;
+        unsigned long long mask = __ballot(match);
+        const unsigned long long failmask = __ballot(match && (v & 1));
+        seen += __popcll(mask);
+        while (mask) {
+            const int bit = __ffsll((long long)mask) - 1;
+            f = ((failmask >> bit) & 1ull) ? (f * keep + w) : (f * keep);
+            mask &= mask - 1ull;
         }
     }
-    __syncthreads();
-    if (threadIdx.x == 0) *done_count = 0;
+    if (lane == 0) { fail_rates[m] = f; motion_done_count[m] = 0; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -752,11 +768,12 @@ struct ResetParams {
     ParcEnvBuffers buf;
 };
 
-__global__ void k_reset_with(const ResetParams P, const int64_t *env_ids, int k, const int *motion_ids, const int *terrain_ids,
-                             const float *t0, const float *xy_noise) {
+__global__ void k_reset_with(const ResetParams P, const int64_t *env_ids, const int *env_ids32, const int *count_dev, int k,
+                             const int *motion_ids, const int *terrain_ids, const float *t0, const float *xy_noise) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (count_dev) k = *count_dev;
     if (i >= k) return;
-    const int e = env_ids ? (int)env_ids[i] : i;
+    const int e = env_ids ? (int)env_ids[i] : (env_ids32 ? env_ids32[i] : i);
     const int mid = motion_ids[i], tid = terrain_ids[i];
     const float t = t0[i];
     const int B = P.B, J = P.J, D = P.D;
@@ -831,12 +848,13 @@ __global__ __launch_bounds__(1024) void k_build_cdf(const float *fail_rates, con
     for (int m = b; m < eend; ++m) { acc += (double)(fmaxf(fail_rates[m], min_w) * motion_weights[m]); cdf[m] = (float)acc; }
 }
 
-__global__ void k_reset_sample(const int64_t *env_ids, int k, int M, int T, const float *cdf, const MotionMeta *meta,
+__global__ void k_reset_sample(const int64_t *env_ids, const int *env_ids32, const int *count_dev, int k, int M, int T, const float *cdf, const MotionMeta *meta,
                                unsigned long long seed, unsigned long long call, int rand_reset, int demo_mode, float noise_scale,
                                const float *start_frac, int *motion_ids, int *terrain_ids, float *t0, float *xy_noise) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (count_dev) k = *count_dev;
     if (i >= k) return;
-    const int e = env_ids ? (int)env_ids[i] : i;
+    const int e = env_ids ? (int)env_ids[i] : (env_ids32 ? env_ids32[i] : i);
     float u[4], v[4];
     philox4(seed, call, (unsigned)e * 2u, u);
     philox4(seed, call, (unsigned)e * 2u + 1u, v);
@@ -880,7 +898,8 @@ struct ParcEnv {
     std::vector<float> h_weights;
     float *d_weights = nullptr, *d_fail = nullptr, *d_cdf = nullptr;
     unsigned char *d_ema = nullptr;
-    int *d_done_list = nullptr, *d_done_count = nullptr;
+    int *d_done_list = nullptr, *d_done_key = nullptr, *d_chunk_count = nullptr, *d_motion_done = nullptr, *d_reset_count = nullptr;
+    int nchunks = 0;
     int *d_tmp_mid = nullptr, *d_tmp_tid = nullptr;
     float *d_tmp_t0 = nullptr, *d_tmp_noise = nullptr, *d_scratch_jr = nullptr, *d_start_frac = nullptr;
     unsigned long long reset_calls = 0;
@@ -894,7 +913,7 @@ extern "C" int parc_abi_version(void) { return PARC_ABI_VERSION; }
 
 static void free_dev(ParcEnv *e) {
     void *ptrs[] = {e->d_tab, e->d_ray, e->d_env_off, e->d_hf, e->d_motion_off, e->d_records, e->d_meta, e->d_weights, e->d_fail,
-                    e->d_cdf, e->d_ema, e->d_done_list, e->d_done_count, e->d_tmp_mid, e->d_tmp_tid, e->d_tmp_t0, e->d_tmp_noise,
+                    e->d_cdf, e->d_ema, e->d_done_list, e->d_done_key, e->d_chunk_count, e->d_motion_done, e->d_reset_count, e->d_tmp_mid, e->d_tmp_tid, e->d_tmp_t0, e->d_tmp_noise,
                     e->d_scratch_jr};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &ev : e->ev) if (ev) (void)hipEventDestroy(ev);
@@ -985,7 +1004,9 @@ extern "C" int parc_env_create(const ParcEnvConfig *cfg, ParcEnv **out) {
         (r = up((void **)&e->d_env_off, cfg->env_offsets_host, sizeof(float) * 3 * N)) != hipSuccess ||
         (r = up((void **)&e->d_ema, nullptr, N)) != hipSuccess ||
         (r = up((void **)&e->d_done_list, nullptr, sizeof(int) * N)) != hipSuccess ||
-        (r = up((void **)&e->d_done_count, nullptr, sizeof(int))) != hipSuccess ||
+        (r = up((void **)&e->d_done_key, nullptr, sizeof(int) * N)) != hipSuccess ||
+        (r = up((void **)&e->d_chunk_count, nullptr, sizeof(int) * 1024)) != hipSuccess ||
+        (r = up((void **)&e->d_reset_count, nullptr, sizeof(int))) != hipSuccess ||
         (r = up((void **)&e->d_tmp_mid, nullptr, sizeof(int) * N)) != hipSuccess ||
         (r = up((void **)&e->d_tmp_tid, nullptr, sizeof(int) * N)) != hipSuccess ||
         (r = up((void **)&e->d_tmp_t0, nullptr, sizeof(float) * N)) != hipSuccess ||
@@ -996,7 +1017,9 @@ extern "C" int parc_env_create(const ParcEnvConfig *cfg, ParcEnv **out) {
     }
     for (auto &ev : e->ev) (void)hipEventCreate(&ev);
     sp.tables = e->d_tab; sp.ray_points = e->d_ray; sp.env_offsets = e->d_env_off;
-    sp.ema_code = e->d_ema; sp.done_list = e->d_done_list; sp.done_count = e->d_done_count;
+    sp.ema_code = e->d_ema; sp.chunk_count = e->d_chunk_count;
+    e->nchunks = (e->N + 1023) / 1024;
+    if (e->nchunks > 1024) { free_dev(e); delete e; return fail(PARC_ERR_INVALID, "num_envs must be <= 1048576 per handle"); }
 
     hipDeviceProp_t prop;
     (void)hipGetDeviceProperties(&prop, cfg->device);
@@ -1042,9 +1065,9 @@ extern "C" int parc_env_load_motions(ParcEnv *e, const ParcMotionClips *c) {
         F += n;
     }
     if (F > (int64_t)1 << 30) return fail(PARC_ERR_INVALID, "too many frames");
-    void *olds[] = {e->d_records, e->d_meta, e->d_weights, e->d_fail, e->d_cdf};
+    void *olds[] = {e->d_records, e->d_meta, e->d_weights, e->d_fail, e->d_cdf, e->d_motion_done};
     for (void *p : olds) if (p) (void)hipFree(p);
-    e->d_records = nullptr; e->d_meta = nullptr; e->d_weights = nullptr; e->d_fail = nullptr; e->d_cdf = nullptr;
+    e->d_records = nullptr; e->d_meta = nullptr; e->d_weights = nullptr; e->d_fail = nullptr; e->d_cdf = nullptr; e->d_motion_done = nullptr;
     float *d_rp = nullptr, *d_rr = nullptr, *d_jr = nullptr, *d_ct = nullptr;
     int *d_fm = nullptr;
     HIPCHK(hipMalloc((void **)&e->d_records, sizeof(float4) * REC_F4 * F));
@@ -1052,6 +1075,8 @@ extern "C" int parc_env_load_motions(ParcEnv *e, const ParcMotionClips *c) {
     HIPCHK(hipMalloc((void **)&e->d_weights, sizeof(float) * M));
     HIPCHK(hipMalloc((void **)&e->d_fail, sizeof(float) * M));
     HIPCHK(hipMalloc((void **)&e->d_cdf, sizeof(float) * M));
+    HIPCHK(hipMalloc((void **)&e->d_motion_done, sizeof(int) * M));
+    HIPCHK(hipMemset(e->d_motion_done, 0, sizeof(int) * M));
     HIPCHK(hipMalloc((void **)&d_rp, sizeof(float) * 3 * F));
     HIPCHK(hipMalloc((void **)&d_rr, sizeof(float) * 4 * F));
     HIPCHK(hipMalloc((void **)&d_jr, sizeof(float) * 4 * J * F));
@@ -1077,7 +1102,7 @@ extern "C" int parc_env_load_motions(ParcEnv *e, const ParcMotionClips *c) {
     (void)hipFree(d_rp); (void)hipFree(d_rr); (void)hipFree(d_jr); (void)hipFree(d_fm);
     if (d_ct) (void)hipFree(d_ct);
     e->M = M; e->F = F; e->have_motions = true;
-    e->sp.M = M; e->sp.records = e->d_records; e->sp.meta = e->d_meta;
+    e->sp.M = M; e->sp.records = e->d_records; e->sp.meta = e->d_meta; e->sp.motion_done_count = e->d_motion_done;
     return PARC_OK;
 }
 
@@ -1132,11 +1157,21 @@ static int check_ready(ParcEnv *e) {
     return PARC_OK;
 }
 
-static int launch_post(ParcEnv *e, int mode, const int64_t *ids, int count, hipStream_t st) {
+static int launch_curriculum(ParcEnv *e, hipStream_t st) {
+    hipLaunchKernelGGL(k_done_scatter, dim3(e->nchunks), dim3(1024), 0, st, e->d_ema, e->sp.buf.motion_ids, e->d_chunk_count, e->nchunks, e->N,
+                       e->d_done_list, e->d_done_key, e->d_reset_count);
+    hipLaunchKernelGGL(k_fail_rate_ema, dim3((e->M + 3) / 4), dim3(256), 0, st, e->d_done_key, e->d_reset_count, e->d_motion_done,
+                       e->d_chunk_count, e->nchunks, e->d_fail, e->M, e->cfg.fail_rate_ema_weight);
+    HIPCHK(hipGetLastError());
+    return PARC_OK;
+}
+
+static int launch_post(ParcEnv *e, int mode, const int64_t *ids, int count, hipStream_t st, const int *ids32 = nullptr,
+                       const int *count_dev = nullptr) {
     if (count <= 0) return PARC_OK;
     const int grid = count < e->grid_waves ? count : e->grid_waves;
-    if (mode == MODE_STEP) hipLaunchKernelGGL(k_env_post<MODE_STEP>, dim3(grid), dim3(64), e->lds_bytes, st, e->sp, ids, count);
-    else hipLaunchKernelGGL(k_env_post<MODE_OBS>, dim3(grid), dim3(64), e->lds_bytes, st, e->sp, ids, count);
+    if (mode == MODE_STEP) hipLaunchKernelGGL(k_env_post<MODE_STEP>, dim3(grid), dim3(64), e->lds_bytes, st, e->sp, ids, ids32, count_dev, count);
+    else hipLaunchKernelGGL(k_env_post<MODE_OBS>, dim3(grid), dim3(64), e->lds_bytes, st, e->sp, ids, ids32, count_dev, count);
     HIPCHK(hipGetLastError());
     return PARC_OK;
 }
@@ -1148,10 +1183,7 @@ extern "C" int parc_env_step(ParcEnv *e, const float *action_dev, void *stream) 
     hipStream_t st = (hipStream_t)stream;
     rc = launch_post(e, MODE_STEP, nullptr, e->N, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_curriculum, dim3(1), dim3(1024), 0, st, e->d_ema, e->sp.buf.motion_ids, e->d_done_list, e->d_done_count,
-                       e->d_fail, e->N, e->cfg.fail_rate_ema_weight);
-    HIPCHK(hipGetLastError());
-    return PARC_OK;
+    return launch_curriculum(e, st);
 }
 
 extern "C" int parc_env_compute_obs(ParcEnv *e, const int64_t *ids, int32_t k, void *stream) {
@@ -1179,7 +1211,8 @@ extern "C" int parc_env_reset_with(ParcEnv *e, const int64_t *ids, int32_t k, co
     if (!mids || !tids || !t0 || !noise || (k > 0 && !ids)) return fail(PARC_ERR_INVALID, "null sample array");
     const int n = k < 0 ? e->N : k;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_reset_with, dim3((n + 63) / 64), dim3(64), 0, st, make_reset_params(e), k < 0 ? nullptr : ids, n, mids, tids, t0, noise);
+    hipLaunchKernelGGL(k_reset_with, dim3((n + 63) / 64), dim3(64), 0, st, make_reset_params(e), k < 0 ? nullptr : ids, (const int *)nullptr,
+                       (const int *)nullptr, n, mids, tids, t0, noise);
     HIPCHK(hipGetLastError());
     return launch_post(e, MODE_OBS, k < 0 ? nullptr : ids, n, st);
 }
@@ -1193,11 +1226,28 @@ extern "C" int parc_env_reset(ParcEnv *e, const int64_t *ids, int32_t k, void *s
     const int n = k < 0 ? e->N : k;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_build_cdf, dim3(1), dim3(1024), 0, st, e->d_fail, e->d_weights, e->cfg.min_motion_weight, e->M, e->d_cdf);
-    hipLaunchKernelGGL(k_reset_sample, dim3((n + 127) / 128), dim3(128), 0, st, k < 0 ? nullptr : ids, n, e->M, e->T, e->d_cdf, e->d_meta,
+    hipLaunchKernelGGL(k_reset_sample, dim3((n + 127) / 128), dim3(128), 0, st, k < 0 ? nullptr : ids, (const int *)nullptr, (const int *)nullptr, n, e->M, e->T, e->d_cdf, e->d_meta,
                        (unsigned long long)e->cfg.seed, e->reset_calls++, e->cfg.rand_reset, e->cfg.demo_mode,
                        e->cfg.rand_root_pos_offset_scale, e->d_start_frac, e->d_tmp_mid, e->d_tmp_tid, e->d_tmp_t0, e->d_tmp_noise);
     HIPCHK(hipGetLastError());
     return parc_env_reset_with(e, k < 0 ? nullptr : ids, k, e->d_tmp_mid, e->d_tmp_tid, e->d_tmp_t0, e->d_tmp_noise, stream);
+}
+
+// Reset every env whose done flag was raised by the last step (base_agent.py:366-370) without the
+// nonzero()/host round trip: the step kernel's compacted done list and its device-side count drive the launch.
+extern "C" int parc_env_reset_done(ParcEnv *e, void *stream) {
+    int rc = check_ready(e);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int n = e->N;
+    hipLaunchKernelGGL(k_build_cdf, dim3(1), dim3(1024), 0, st, e->d_fail, e->d_weights, e->cfg.min_motion_weight, e->M, e->d_cdf);
+    hipLaunchKernelGGL(k_reset_sample, dim3((n + 127) / 128), dim3(128), 0, st, (const int64_t *)nullptr, e->d_done_list, e->d_reset_count, n, e->M,
+                       e->T, e->d_cdf, e->d_meta, (unsigned long long)e->cfg.seed, e->reset_calls++, e->cfg.rand_reset, e->cfg.demo_mode,
+                       e->cfg.rand_root_pos_offset_scale, e->d_start_frac, e->d_tmp_mid, e->d_tmp_tid, e->d_tmp_t0, e->d_tmp_noise);
+    hipLaunchKernelGGL(k_reset_with, dim3((n + 63) / 64), dim3(64), 0, st, make_reset_params(e), (const int64_t *)nullptr, e->d_done_list,
+                       e->d_reset_count, n, e->d_tmp_mid, e->d_tmp_tid, e->d_tmp_t0, e->d_tmp_noise);
+    HIPCHK(hipGetLastError());
+    return launch_post(e, MODE_OBS, nullptr, n, st, e->d_done_list, e->d_reset_count);
 }
 
 extern "C" int parc_env_get_fail_rates(ParcEnv *e, float *out, int32_t M) {
@@ -1301,8 +1351,8 @@ extern "C" int parc_env_profile_step(ParcEnv *e, const float *action_dev, void *
         rc = launch_post(e, MODE_STEP, nullptr, e->N, st);
         if (rc) return rc;
         HIPCHK(hipEventRecord(e->ev[1], st));
-        hipLaunchKernelGGL(k_curriculum, dim3(1), dim3(1024), 0, st, e->d_ema, e->sp.buf.motion_ids, e->d_done_list, e->d_done_count,
-                           e->d_fail, e->N, e->cfg.fail_rate_ema_weight);
+        rc = launch_curriculum(e, st);
+        if (rc) return rc;
         HIPCHK(hipEventRecord(e->ev[2], st));
         HIPCHK(hipEventSynchronize(e->ev[2]));
         float a = 0.f, b = 0.f;

@@ -224,6 +224,12 @@ class HipParkourEnv(base_env.BaseEnv):
         self._update_info()
         return self._obs_buf, self._info
 
+    def reset_done(self):
+        """``BaseAgent._reset_done_envs`` without the ``nonzero()`` host sync: every env whose done flag was raised by
+        the last ``step`` is re-sampled and reset on the device (``parc_env_reset_done``)."""
+        L.check(self._lib.parc_env_reset_done(self._handle, self._stream()))
+        return self._obs_buf, self._info
+
     def reset_with(self, env_ids, motion_ids, terrain_ids, t0, xy_noise):
         """Reset with the random draws injected (parity tests; ``parc_env_reset_with``)."""
         dev = self._device

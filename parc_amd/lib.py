@@ -107,6 +107,7 @@ def load():
     lib.parc_env_reset.argtypes = [vp, vp, C.c_int32, vp]
     lib.parc_env_reset_with.argtypes = [vp, vp, C.c_int32, vp, vp, vp, vp, vp]
     lib.parc_env_compute_obs.argtypes = [vp, vp, C.c_int32, vp]
+    lib.parc_env_reset_done.argtypes = [vp, vp]
     lib.parc_env_get_fail_rates.argtypes = [vp, f32p, C.c_int32]
     lib.parc_env_set_fail_rates.argtypes = [vp, f32p, C.c_int32]
     lib.parc_env_get_motion_info.argtypes = [vp, f32p, f32p, C.c_int32]
@@ -127,7 +128,7 @@ def load():
 EXPORTED_SYMBOLS = [
     "parc_last_error", "parc_abi_version", "parc_env_create", "parc_env_destroy", "parc_env_obs_dim",
     "parc_env_load_motions", "parc_env_load_terrain", "parc_env_bind_buffers", "parc_env_step", "parc_env_reset",
-    "parc_env_reset_with", "parc_env_compute_obs", "parc_env_get_fail_rates", "parc_env_set_fail_rates",
+    "parc_env_reset_with", "parc_env_reset_done", "parc_env_compute_obs", "parc_env_get_fail_rates", "parc_env_set_fail_rates",
     "parc_env_get_motion_info", "parc_env_set_rand_reset", "parc_env_set_start_time_fraction", "parc_dof_to_rot",
     "parc_rot_to_dof", "parc_forward_kinematics", "parc_calc_motion_frame", "parc_env_get_frame_vel_tables",
     "parc_env_profile_step",

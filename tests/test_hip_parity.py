@@ -282,3 +282,36 @@ def test_full_size_properties(tmp_path):
     assert np.all(np.abs(counts - n / 4) < 5 * np.sqrt(n * 0.25 * 0.75))
     # time offsets inside the clip
     assert (env._motion_time_offsets >= 0).all() and (env._motion_time_offsets <= env._motion_lengths[env._motion_ids.long()]).all()
+
+
+def test_reset_done_device_side(tmp_path):
+    """parc_env_reset_done == reset(nonzero(done)) semantics, without the host round trip."""
+    import torch
+    from gpu_helpers import default_config, write_motion_yaml, to_np
+    from helpers import CLIPS4
+    from parc_amd.envs.hip_parkour_env import HipParkourEnv
+    n = 8192
+    cfg = default_config()
+    cfg["env"]["dm"]["motion_file"] = write_motion_yaml(tmp_path, CLIPS4, [1, 1, 1, 1])
+    env = HipParkourEnv(cfg, n, "cuda:0", False, seed=11)
+    env.reset()
+    total_done = 0
+    for s in range(40):
+        env._char_root_pos += 0.05 * torch.randn_like(env._char_root_pos)  # drift -> some envs fail
+        _, _, done, _ = env.step(None)
+        d = to_np(done).copy()
+        ts_before = to_np(env._timestep_buf).copy(); ep_before = to_np(env._ep_num_buf).copy()
+        obs_before = to_np(env._obs_buf).copy()
+        env.reset_done()
+        ts = to_np(env._timestep_buf); ep = to_np(env._ep_num_buf)
+        was_done = d != 0
+        total_done += was_done.sum()
+        assert np.all(ts[was_done] == 0) and np.array_equal(ts[~was_done], ts_before[~was_done])
+        assert np.array_equal(ep, ep_before + was_done)
+        assert np.all(to_np(env._done_buf)[was_done] == 0)
+        assert np.array_equal(to_np(env._obs_buf)[~was_done], obs_before[~was_done])
+        if was_done.any():
+            assert not np.array_equal(to_np(env._obs_buf)[was_done], obs_before[was_done])
+    assert total_done > 100
+    fr = env.get_fail_rates().numpy()
+    assert np.all(fr > 0) and np.all(fr <= 1.0) and np.any(fr < 1.0)
