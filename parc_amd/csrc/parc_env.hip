@@ -35,7 +35,7 @@ using namespace parc;
 #define REC_Q_CONTACT 16     // float4 #16..19 = contacts
 #define REC_Q_VEL 20         // float4 #20 = root_vel, #21 = root_ang_vel, #22.. = dof_vel
 
-struct DevTables { // per-lane indexed tables, staged into LDS once per wave
+struct HierTables { // joint hierarchy: the part of the per-body tables every wave stages into LDS
     int parent[16];
     int jtype[16];
     int dof_idx[16];
@@ -43,8 +43,15 @@ struct DevTables { // per-lane indexed tables, staged into LDS once per wave
     float lt[16][4];
     float lr[16][4];
     int fk_paths[PARC_MAX_FK_PATHS][PARC_MAX_FK_DEPTH];
-    float tstep[8];          // control_dt * tar_obs_steps (fp32 product, mgdm_dm_util.py:232)
     int key_ids[8];
+    int key_slot[16]; // body -> index into key_ids, or -1
+};
+
+#define TILE_MAX_CELLS 320 // the terrain tile aliases the FK scratch (80 float4)
+
+struct DevTables { // global memory; `h` is staged into LDS, the rest is read once per env
+    HierTables h;
+    float tstep[8];          // control_dt * tar_obs_steps (fp32 product, mgdm_dm_util.py:232)
     float joint_err_w[16];
     float dof_err_w[PARC_MAX_DOFS];
     float contact_w[16];
@@ -68,11 +75,15 @@ struct StepParams {
     int early_term, pose_term, track_root, track_root_h, tracking, body_pos_from_fk;
     // terrain
     const float *hf; int X, Y; float min_x, min_y, dx, dy; int tile_r;
+    unsigned tile_mul;   // idx / (2 tile_r + 1) == (idx * tile_mul) >> 16 for every tile cell (checked on the host)
+    float tstep[8];      // control_dt * tar_obs_steps (fp32 product, mgdm_dm_util.py:232)
     // tables
     const float4 *records; const MotionMeta *meta; const float *motion_offsets; const float *env_offsets;
     const float *ray_points; const DevTables *tables;
     // curriculum hand-off
-    unsigned char *ema_code; int *chunk_count; int *motion_done_count;
+    unsigned char *ema_code;
+    unsigned *stamp_out; // diagnostic builds only
+    float4 *prep;        // [N][16]: slot 0 = (cos h, sin h, hinv.z, hinv.w), slots 1..B-1 = character joint quats
     ParcEnvBuffers buf;
 };
 
@@ -123,431 +134,548 @@ __device__ __forceinline__ int cell_index(float p, float mn, float d) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// the step kernel: IGEnv._post_physics_step (ig_env.py:368-377) for one env per wave
+// k_env_prep: one THREAD per env for the work that is scalar per env and transcendental-heavy — heading,
+// inverse heading quaternion, cos/sin of the heading for the ray fan, and dof -> joint quaternion of the
+// character (kin_char_model.py:586; torch_util.py:502-530).  In the wave-per-env kernel these ran with 1-14
+// active lanes; here 64 envs share every instruction.  Output: a 256-byte record per env (L2/Infinity-Cache
+// resident between the two launches).
 // ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_env_prep(const StepParams *__restrict__ Pp, const int64_t *__restrict__ env_ids,
+                                                 const int *__restrict__ env_ids32, const int *__restrict__ count_dev, int count) {
+    const StepParams &P = *Pp;
+    if (count_dev) count = *count_dev;
+    const int it = blockIdx.x * blockDim.x + threadIdx.x;
+    if (it >= count) return;
+    const int e = env_ids ? (int)env_ids[it] : (env_ids32 ? env_ids32[it] : it);
+    const DevTables *__restrict__ T = P.tables;
+    const float4 rr = *(const float4 *)(P.buf.char_root_rot + 4 * (size_t)e);
+    const float heading = calc_heading(rr);
+    const Q4 hinv = heading_quat_inv(heading);
+    float4 *out = P.prep + (size_t)e * 16;
+    out[0] = make_float4(cosf(heading), sinf(heading), hinv.z, hinv.w);
+    const float *dof = P.buf.char_dof_pos + (size_t)e * P.D;
+    for (int j = 1; j < P.B; ++j) {
+        const int ty = T->h.jtype[j], di = T->h.dof_idx[j];
+        Q4 q = mk4(0.f, 0.f, 0.f, 1.f);
+        if (ty == PARC_JOINT_HINGE) q = axis_angle_to_quat(mk3(T->h.axis[j][0], T->h.axis[j][1], T->h.axis[j][2]), dof[di]);
+        else if (ty == PARC_JOINT_SPHERICAL) q = exp_map_to_quat(mk3(dof[di], dof[di + 1], dof[di + 2]));
+        out[j] = q;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// the step kernel: IGEnv._post_physics_step (ig_env.py:368-377), one env per 64-lane workgroup
+// ------------------------------------------------------------------------------------------------
+// Diagnostic build only (-DPARC_STAMPS): per-phase s_memtime stamps of lane 0 go to a debug buffer that no
+// other code reads; the shipped library is built without it.
+#ifdef PARC_STAMPS
+#define STAMP(i) do { if (lane == 0) s_stamp[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
 #define MODE_STEP 0
 #define MODE_OBS 1
+#define RAY_UNROLL 8
+
+__device__ __forceinline__ float wave_sum(float v) { // butterfly over the 64 lanes; every lane gets the total
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = v + __shfl_xor(v, off, 64);
+    return v;
+}
 
 template <int MODE>
-__global__ __launch_bounds__(64) void k_env_post(const StepParams P, const int64_t *__restrict__ env_ids,
+__global__ __launch_bounds__(64, 4) void k_env_post(const StepParams *__restrict__ Pp, const int64_t *__restrict__ env_ids,
                                                  const int *__restrict__ env_ids32, const int *__restrict__ count_dev, int count) {
-    extern __shared__ __align__(16) float s_dyn[]; // [obs_dim rounded to 4][tile]
-    __shared__ DevTables s_tab;
+    const StepParams &P = *Pp; // uniform, read-only: scalar loads where the value is used
+    extern __shared__ __align__(16) float s_obs[]; // staged observation prefix [0, off_tarc)
+    __shared__ HierTables s_tab;
     __shared__ float4 s_q[8][16];   // row r: quats 0..14 (0 = root), slot 15 = root position
-    __shared__ float4 s_bp[8][16];  // FK body positions per row
+    __shared__ float4 s_fk[80];     // FK positions: rows 0,1 all bodies [r*16+b]; target rows key slots [32+(r-2)*8+k]
     __shared__ float4 s_br[2][16];  // body rotations of char/ref (tracking error only)
     __shared__ float4 s_cbp[16];    // simulator rigid-body positions of the character
     __shared__ float4 s_rpo[8];     // per target row: heading-frame root offset
-    __shared__ float s_cdof[PARC_MAX_DOFS], s_cdofv[PARC_MAX_DOFS];
+    __shared__ float s_cdofv[PARC_MAX_DOFS];
     __shared__ float4 s_refvel[12]; // record float4 #20..: root_vel, root_ang_vel, dof_vel
     __shared__ float s_refct[16];
     __shared__ float s_cfn[16];
-    __shared__ float s_red[4][64];
-    __shared__ int s_bi0[8], s_bi1[8];
-    __shared__ float s_bb[8];
+#ifdef PARC_STAMPS
+    __shared__ unsigned long long s_stamp[16];
+#endif
+    float *s_tile = (float *)s_fk;  // the terrain tile is dead before FK writes s_fk
 
     const int lane = threadIdx.x;
-    float *s_obs = s_dyn;
-    const int obs_pad = (P.obs_dim + 3) & ~3;
-    float *s_tile = s_dyn + obs_pad;
-
-    for (int i = lane; i < (int)(sizeof(DevTables) / 4); i += 64) ((int *)&s_tab)[i] = ((const int *)P.tables)[i];
-    __syncthreads();
-
-    const int B = P.B, D = P.D, S = P.S, K = P.K;
     if (count_dev) count = *count_dev; // device-side list (reset_done): no host round trip
+    const int it = blockIdx.x;
+    if (it >= count) return;
+    int e = env_ids ? (int)env_ids[it] : (env_ids32 ? env_ids32[it] : it);
+    e = __builtin_amdgcn_readfirstlane(e);
+    STAMP(0);
 
-    for (int it = blockIdx.x; it < count; it += gridDim.x) {
-        int e = env_ids ? (int)env_ids[it] : (env_ids32 ? env_ids32[it] : it);
-        e = __builtin_amdgcn_readfirstlane(e);
+    const int B = P.B, D = P.D, S = P.S, K = P.K, J = P.J;
+    const DevTables *__restrict__ T = P.tables;
 
-        // ---- bookkeeping + time (ig_env.py:391-394, dm_env.py:547-552) -------------------------
-        const int mid = P.buf.motion_ids[e];
-        const int tid = P.buf.terrain_ids[e];
-        const float toff = P.buf.time_offsets[e];
-        int ts = P.buf.timestep[e];
-        if (MODE == MODE_STEP) ts += 1;
-        const float time = P.dt_f * (float)ts;
-        const float mt = time + toff;
-        const MotionMeta meta = P.meta[mid];
-        const float eox = P.env_offsets[3 * e + 0], eoy = P.env_offsets[3 * e + 1], eoz = P.env_offsets[3 * e + 2];
-        const float *mo = P.motion_offsets + 2 * ((size_t)mid * P.T + tid);
-        const float offx = mo[0] - eox, offy = mo[1] - eoy; // dm_env.py:556
+    float *orow = P.buf.obs + (size_t)e * P.obs_dim;
 
-        // ---- character root state, heading ----------------------------------------------------
-        const float *crp = P.buf.char_root_pos + 3 * (size_t)e;
-        const float *crr = P.buf.char_root_rot + 4 * (size_t)e;
-        const V3 root_pos = mk3(crp[0], crp[1], crp[2]);
-        const Q4 root_rot = mk4(crr[0], crr[1], crr[2], crr[3]);
-        const float heading = calc_heading(root_rot);
-        const Q4 hinv = heading_quat_inv(heading);
-
-        // dof state -> LDS, dof velocities straight into the observation row
-        if (lane < D) {
-            float dp = P.buf.char_dof_pos[(size_t)e * D + lane];
-            float dv = P.buf.char_dof_vel[(size_t)e * D + lane];
-            s_cdof[lane] = dp;
-            s_cdofv[lane] = dv;
-            s_obs[P.off_dofvel + lane] = dv;
-        }
-        // root velocities in the heading frame (ig_char_env.py:593-597)
-        if (lane == 62 || lane == 63) {
-            const float *v = (lane == 62 ? P.buf.char_root_vel : P.buf.char_root_ang_vel) + 3 * (size_t)e;
-            V3 r = quat_rotate(hinv, mk3(v[0], v[1], v[2]));
-            int o = lane == 62 ? 6 : 9;
-            s_obs[o + 0] = r.x; s_obs[o + 1] = r.y; s_obs[o + 2] = r.z;
-        }
-        // contact flags + clamped force norms (ig_parkour_env.py:655-662, mgdm_dm_util.py:505-508)
-        if (lane >= 32 && lane < 32 + B) {
-            int b = lane - 32;
-            const float *f = P.buf.contact_forces + 3 * ((size_t)e * B + b);
-            float n = norm3(mk3(f[0], f[1], f[2]));
-            s_obs[P.off_cc + b] = n > 1e-5f ? 1.f : 0.f;
-            s_cfn[b] = fminf(n, 1.0f);
-        }
-        if (!P.body_pos_from_fk && lane >= 48 && lane < 48 + B) {
-            int b = lane - 48;
-            const float *p = P.buf.char_body_pos + 3 * ((size_t)e * B + b);
-            s_cbp[b] = make_float4(p[0], p[1], p[2], 0.f);
-        }
-        __syncthreads();
-
-        // ---- 8 rows x 16 lanes: quaternions of char / ref / targets + tan-norm observations ------
-        for (int p = 0; p < 2; ++p) {
-            const int r = p * 4 + (lane >> 4);
-            const int i = lane & 15;
-            if (r < 2 + S) {
-                float4 res = make_float4(0.f, 0.f, 0.f, 1.f);
-                if (r == 0) { // character: dof -> quat (kin_char_model.py:586)
-                    if (i == 0) res = root_rot;
-                    else if (i == 15) res = make_float4(root_pos.x, root_pos.y, root_pos.z, 0.f);
-                    else if (i < B) res = joint_dof_to_rot(s_tab.jtype[i], s_tab.axis[i], &s_cdof[s_tab.dof_idx[i]]);
-                } else { // reference motion sample (motion_lib.py:94-128)
-                    const int s = r - 1;
-                    const float t = s == 0 ? mt : mt + s_tab.tstep[s - 1];
-                    const Blend bl = frame_blend(meta, t);
-                    const float4 *r0 = P.records + (size_t)bl.i0 * REC_F4;
-                    const float4 *r1 = P.records + (size_t)bl.i1 * REC_F4;
-                    const float4 A = r0[i], Bv = r1[i];
-                    if (i == 15) {
-                        const float a = 1.0f - bl.b;
-                        res.x = a * A.x + bl.b * Bv.x;
-                        res.y = a * A.y + bl.b * Bv.y;
-                        res.z = a * A.z + bl.b * Bv.z;
-                        res.w = 0.f;
-                        if (meta.loop == PARC_LOOP_WRAP) { // _calc_loop_offset :440
-                            const float ph = floorf(t / meta.length);
-                            res.x = res.x + ph * meta.dx; res.y = res.y + ph * meta.dy; res.z = res.z + ph * meta.dz;
-                        }
-                        res.x = res.x + offx; // _move_to_motion_terrain dm_env.py:554
-                        res.y = res.y + offy;
-                        s_bi0[s] = bl.i0; s_bi1[s] = bl.i1; s_bb[s] = bl.b;
-                    } else if (i < B) {
-                        res = slerp(A, Bv, bl.b);
-                    }
-                }
-                s_q[r][i] = res;
-                if (r == 1) { // optional mirrors of the reference's ref_* tensors
-                    if (i == 0 && P.buf.ref_root_rot) *(float4 *)(P.buf.ref_root_rot + 4 * (size_t)e) = res;
-                    if (i >= 1 && i < B && P.buf.ref_joint_rot) *(float4 *)(P.buf.ref_joint_rot + 4 * ((size_t)e * P.J + i - 1)) = res;
-                    if (i == 15 && P.buf.ref_root_pos) {
-                        float *o = P.buf.ref_root_pos + 3 * (size_t)e;
-                        o[0] = res.x; o[1] = res.y; o[2] = res.z;
-                    }
-                } else { // observation pieces (ig_char_env.py:582, mgdm_dm_util.py:405)
-                    const int base = r == 0 ? 0 : P.off_tar + (r - 2) * P.tar_w;
-                    if (i < B) {
-                        const Q4 qq = i == 0 ? quat_mul(hinv, res) : res;
-                        float tn[6];
-                        quat_to_tan_norm(qq, tn);
-                        const int o = r == 0 ? (i == 0 ? 0 : 12 + 6 * (i - 1)) : base + 3 + 6 * i;
+    // ================= prefetch: every global load of this env is issued before any is consumed =================
+    // (a) loads that only need the env id go first, so they overlap the scalar bookkeeping chain below
+    constexpr int HW = (int)(sizeof(HierTables) / 4);
+    constexpr int HN = (HW + 63) / 64;
+    int tabreg[HN];
 #pragma unroll
-                        for (int c = 0; c < 6; ++c) s_obs[o + c] = tn[c];
-                    } else if (i == 15 && r >= 2) {
-                        V3 rpo = quat_rotate(hinv, mk3(res.x - root_pos.x, res.y - root_pos.y, res.z - root_pos.z));
-                        s_obs[base + 0] = rpo.x; s_obs[base + 1] = rpo.y; s_obs[base + 2] = rpo.z;
-                        s_rpo[r] = make_float4(rpo.x, rpo.y, rpo.z, 0.f);
-                    }
-                }
-            }
-        }
-        __syncthreads();
-
-        // ---- contacts of the 1+S samples and the velocity block of sample 0 ---------------------
-        if (lane < 4 * (1 + S)) {
-            const int s = lane >> 2, c = lane & 3;
-            const float b = s_bb[s], a = 1.0f - b;
-            const float4 A = P.records[(size_t)s_bi0[s] * REC_F4 + REC_Q_CONTACT + c];
-            const float4 Bv = P.records[(size_t)s_bi1[s] * REC_F4 + REC_Q_CONTACT + c];
-            const float v[4] = {a * A.x + b * Bv.x, a * A.y + b * Bv.y, a * A.z + b * Bv.z, a * A.w + b * Bv.w};
+    for (int i = 0; i < HN; ++i) { const int w = lane + 64 * i; tabreg[i] = w < HW ? ((const int *)&T->h)[w] : 0; }
+    float dofv = 0.f;
+    if (lane < D) dofv = P.buf.char_dof_vel[(size_t)e * D + lane];
+    float aux0 = 0.f, aux1 = 0.f, aux2 = 0.f; // lanes 32..32+B: contact force; 30/31: root (ang) vel
+    {
+        const float *src = nullptr;
+        if (lane >= 32 && lane < 32 + B) src = P.buf.contact_forces + 3 * ((size_t)e * B + (lane - 32));
+        else if (lane == 30) src = P.buf.char_root_vel + 3 * (size_t)e;
+        else if (lane == 31) src = P.buf.char_root_ang_vel + 3 * (size_t)e;
+        if (src) { aux0 = src[0]; aux1 = src[1]; aux2 = src[2]; }
+    }
+    float bpx = 0.f, bpy = 0.f, bpz = 0.f;
+    if (!P.body_pos_from_fk && lane < B) {
+        const float *src = P.buf.char_body_pos + 3 * ((size_t)e * B + lane);
+        bpx = src[0]; bpy = src[1]; bpz = src[2];
+    }
+    const int qi = lane & 15;
+    float4 prepq = make_float4(0.f, 0.f, 0.f, 1.f);
+    if (lane < 16) prepq = P.prep[(size_t)e * 16 + lane]; // slot 0 heading terms, 1..B-1 character joint quats (k_env_prep)
+    float2 rayp[RAY_UNROLL];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int bd = 4 * c + k;
-                if (bd < B) {
-                    if (s == 0) {
-                        s_refct[bd] = v[k];
-                        if (P.buf.ref_contacts) P.buf.ref_contacts[(size_t)e * B + bd] = v[k];
-                    } else {
-                        s_obs[P.off_tarc + (s - 1) * B + bd] = v[k];
+    for (int i = 0; i < RAY_UNROLL; ++i) {
+        const int r = lane + 64 * i;
+        rayp[i] = r < P.R ? ((const float2 *)P.ray_points)[r] : make_float2(0.f, 0.f);
+    }
+
+    // (b) bookkeeping + time (ig_env.py:391-394, dm_env.py:547-552): uniform, scalar loads
+    const int mid = P.buf.motion_ids[e];
+    const int tid = P.buf.terrain_ids[e];
+    const float toff = P.buf.time_offsets[e];
+    int ts = P.buf.timestep[e];
+    if (MODE == MODE_STEP) ts += 1;
+    const float time = P.dt_f * (float)ts;
+    const float mt = time + toff;
+    const MotionMeta meta = P.meta[mid];
+    const float eox = P.env_offsets[3 * e + 0], eoy = P.env_offsets[3 * e + 1], eoz = P.env_offsets[3 * e + 2];
+    const float *mo = P.motion_offsets + 2 * ((size_t)mid * P.T + tid);
+    const float offx = mo[0] - eox, offy = mo[1] - eoy; // dm_env.py:556
+    const float *crp = P.buf.char_root_pos + 3 * (size_t)e;
+    const float *crr = P.buf.char_root_rot + 4 * (size_t)e;
+    const V3 root_pos = mk3(crp[0], crp[1], crp[2]);
+    const Q4 root_rot = mk4(crr[0], crr[1], crr[2], crr[3]);
+    const float gx = root_pos.x + eox, gy = root_pos.y + eoy, gz = root_pos.z + eoz; // ig_parkour_env.py:522
+
+    // (c) reference motion: rows 1..1+S (row = pass*4 + lane/16), two 512-byte frame records per sample
+    float4 fA[2], fB[2];
+    Blend bl[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int r = p * 4 + (lane >> 4);
+        float t = mt;
+#pragma unroll
+        for (int q = 0; q < PARC_MAX_TAR_STEPS; ++q) t = (r - 2 == q) ? mt + P.tstep[q] : t;
+        bl[p] = frame_blend(meta, t);
+        fA[p] = make_float4(0.f, 0.f, 0.f, 1.f); fB[p] = fA[p];
+        if (r >= 1 && r < 2 + S) {
+            fA[p] = P.records[(size_t)bl[p].i0 * REC_F4 + qi];
+            fB[p] = P.records[(size_t)bl[p].i1 * REC_F4 + qi];
+        }
+    }
+    // (d) contacts of the 1+S samples (lanes < 4(1+S)) / velocity block of sample 0 (lanes 32..)
+    float4 cA = make_float4(0.f, 0.f, 0.f, 0.f), cB = cA;
+    float cblend = 0.f;
+    const int nvel = 2 + (D + 3) / 4;
+    if (lane < 4 * (1 + S)) {
+        const int s = lane >> 2, c = lane & 3;
+        float t = mt;
+#pragma unroll
+        for (int q = 0; q < PARC_MAX_TAR_STEPS; ++q) t = (s - 1 == q) ? mt + P.tstep[q] : t;
+        const Blend b2 = frame_blend(meta, t);
+        cblend = b2.b;
+        cA = P.records[(size_t)b2.i0 * REC_F4 + REC_Q_CONTACT + c];
+        cB = P.records[(size_t)b2.i1 * REC_F4 + REC_Q_CONTACT + c];
+    } else if (lane >= 32 && lane < 32 + nvel) { // velocities come from frame idx0 un-interpolated (:103-109)
+        const Blend b2 = frame_blend(meta, mt);
+        cA = P.records[(size_t)b2.i0 * REC_F4 + REC_Q_VEL + (lane - 32)];
+    }
+    // (e) terrain tile cells
+    const int tr = P.tile_r, TW = 2 * tr + 1, ncell = tr >= 0 ? TW * TW : 0;
+    const int ox = cell_index(gx, P.min_x, P.dx) - tr, oy = cell_index(gy, P.min_y, P.dy) - tr;
+    float tilev[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int idx = lane + 64 * i;
+        tilev[i] = 0.f;
+        if (idx < ncell) {
+            const int a = (int)(((unsigned)idx * P.tile_mul) >> 16), bq = idx - a * TW;
+            const int cx = min(max(ox + a, 0), P.X - 1), cy = min(max(oy + bq, 0), P.Y - 1);
+            tilev[i] = P.hf[(size_t)cx * P.Y + cy];
+        }
+    }
+
+    // ================= heading terms from k_env_prep (uniform), LDS fills =================
+    const float ch = __shfl(prepq.x, 0, 64), sh = __shfl(prepq.y, 0, 64);
+    const Q4 hinv = mk4(0.f, 0.f, __shfl(prepq.z, 0, 64), __shfl(prepq.w, 0, 64)); // axis_angle_to_quat(z, -heading): x = y = 0 exactly
+#pragma unroll
+    for (int i = 0; i < HN; ++i) { const int w = lane + 64 * i; if (w < HW) ((int *)&s_tab)[w] = tabreg[i]; }
+    if (lane < D) {
+        s_cdofv[lane] = dofv;
+        s_obs[P.off_dofvel + lane] = dofv;
+    }
+    if (lane == 30 || lane == 31) { // root velocities in the heading frame (ig_char_env.py:593-597)
+        const V3 r = quat_rotate(hinv, mk3(aux0, aux1, aux2));
+        const int o = lane == 30 ? 6 : 9;
+        s_obs[o + 0] = r.x; s_obs[o + 1] = r.y; s_obs[o + 2] = r.z;
+    }
+    if (lane >= 32 && lane < 32 + B) { // contact flags + clamped force norms (ig_parkour_env.py:655-662, mgdm_dm_util.py:505-508)
+        const float n = norm3(mk3(aux0, aux1, aux2));
+        orow[P.off_cc + (lane - 32)] = n > 1e-5f ? 1.f : 0.f;
+        s_cfn[lane - 32] = fminf(n, 1.0f);
+    }
+    if (!P.body_pos_from_fk && lane < B) s_cbp[lane] = make_float4(bpx, bpy, bpz, 0.f);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { const int idx = lane + 64 * i; if (idx < ncell) s_tile[idx] = tilev[i]; }
+    __syncthreads();
+    STAMP(1);
+
+    // ================= height rays (mgdm_dm_util.py:128-145; terrain_util.py:146-156) =================
+    {
+        float *hrow = orow + P.off_hf;
+        float *hmirror = P.buf.ray_hfs ? P.buf.ray_hfs + (size_t)e * P.R : nullptr;
+        for (int base = 0; base < P.R; base += 64 * RAY_UNROLL) {
+            if (base > 0) {
+#pragma unroll
+                for (int i = 0; i < RAY_UNROLL; ++i) { const int r = base + lane + 64 * i; rayp[i] = r < P.R ? ((const float2 *)P.ray_points)[r] : make_float2(0.f, 0.f); }
+            }
+#pragma unroll
+            for (int i = 0; i < RAY_UNROLL; ++i) {
+                const int r = base + lane + 64 * i;
+                if (r < P.R) {
+                    const float px = (rayp[i].x * ch - rayp[i].y * sh) + gx; // rotate_2d_vec torch_util.py:651
+                    const float py = (rayp[i].x * sh + rayp[i].y * ch) + gy;
+                    const int ix = cell_index(px, P.min_x, P.dx), iy = cell_index(py, P.min_y, P.dy);
+                    const int a = ix - ox, bq = iy - oy;
+                    float h;
+                    if (a >= 0 && a < TW && bq >= 0 && bq < TW) {
+                        h = s_tile[a * TW + bq];
+                    } else { // outside the staged tile (cannot happen for the default fan; kept for safety)
+                        const int cx = min(max(ix, 0), P.X - 1), cy = min(max(iy, 0), P.Y - 1);
+                        h = P.hf[(size_t)cx * P.Y + cy];
                     }
-                }
-            }
-        } else if (lane >= 32 && lane < 32 + 2 + (D + 3) / 4) { // velocities come from frame idx0 un-interpolated (:103-109)
-            const int c = lane - 32;
-            const float4 v = P.records[(size_t)s_bi0[0] * REC_F4 + REC_Q_VEL + c];
-            s_refvel[c] = v;
-            if (c == 0 && P.buf.ref_root_vel) { float *o = P.buf.ref_root_vel + 3 * (size_t)e; o[0] = v.x; o[1] = v.y; o[2] = v.z; }
-            if (c == 1 && P.buf.ref_root_ang_vel) { float *o = P.buf.ref_root_ang_vel + 3 * (size_t)e; o[0] = v.x; o[1] = v.y; o[2] = v.z; }
-            if (c >= 2 && P.buf.ref_dof_vel) {
-                const float vv[4] = {v.x, v.y, v.z, v.w};
-                for (int k = 0; k < 4; ++k) { int d = 4 * (c - 2) + k; if (d < D) P.buf.ref_dof_vel[(size_t)e * D + d] = vv[k]; }
-            }
-        }
-
-        // ---- FK: row k = lane>>3, root-to-leaf chain c = lane&7 (kin_char_model.py:617-649) -----
-        {
-            const int k = lane >> 3, c = lane & 7;
-            if (k < 2 + S) {
-                Q4 prot = s_q[k][0];
-                float4 pp = s_q[k][15];
-                V3 ppos = mk3(pp.x, pp.y, pp.z);
-                if (c == 0) {
-                    s_bp[k][0] = make_float4(ppos.x, ppos.y, ppos.z, 0.f);
-                    if (k < 2 && P.tracking) s_br[k][0] = prot;
-                }
-#pragma unroll 1
-                for (int d = 0; d < PARC_MAX_FK_DEPTH; ++d) {
-                    const int b = s_tab.fk_paths[c][d];
-                    if (b < 0) break;
-                    const V3 wt = quat_rotate(prot, mk3(s_tab.lt[b][0], s_tab.lt[b][1], s_tab.lt[b][2]));
-                    ppos = mk3(ppos.x + wt.x, ppos.y + wt.y, ppos.z + wt.z);
-                    const Q4 lr = mk4(s_tab.lr[b][0], s_tab.lr[b][1], s_tab.lr[b][2], s_tab.lr[b][3]);
-                    prot = quat_mul(prot, quat_mul(lr, s_q[k][b]));
-                    s_bp[k][b] = make_float4(ppos.x, ppos.y, ppos.z, 0.f);
-                    if (k < 2 && P.tracking) s_br[k][b] = prot;
+                    h = h - gz;
+                    h = fminf(fmaxf(h, P.min_obs_h), P.max_obs_h);
+                    hrow[r] = h; // 256 contiguous bytes per wave store: no staging needed
+                    if (hmirror) hmirror[r] = h;
                 }
             }
         }
-        __syncthreads();
-        if (P.body_pos_from_fk && lane < B) s_cbp[lane] = s_bp[0][lane];
+    }
+    STAMP(2);
 
-        // ---- key-body observations (ig_char_env.py:603-617, mgdm_dm_util.py:415-440) ------------
-        if (lane < 8 * (1 + S)) {
-            const int row = lane >> 3, kk = lane & 7; // row 0 = char, 1.. = target rows 2..
-            if (kk < K) {
-                const int b = s_tab.key_ids[kk];
-                if (row == 0) {
-                    const float4 kp = s_bp[0][b];
-                    const V3 rl = quat_rotate(hinv, mk3(kp.x - root_pos.x, kp.y - root_pos.y, kp.z - root_pos.z));
-                    const int o = P.off_key + 3 * kk;
-                    s_obs[o] = rl.x; s_obs[o + 1] = rl.y; s_obs[o + 2] = rl.z;
+    // ================= 8 rows x 16 lanes: quaternions of char / ref / targets + tan-norm observations =================
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int r = p * 4 + (lane >> 4);
+        const int i = qi;
+        if (r < 2 + S) {
+            float4 res = make_float4(0.f, 0.f, 0.f, 1.f);
+            if (r == 0) { // character: dof -> quat (kin_char_model.py:586)
+                if (i == 0) res = root_rot;
+                else if (i == 15) res = make_float4(root_pos.x, root_pos.y, root_pos.z, 0.f);
+                else if (i < B) res = prepq;
+            } else { // reference motion sample (motion_lib.py:94-128)
+                const float4 A = fA[p], Bv = fB[p];
+                const float bb = bl[p].b;
+                if (i == 15) {
+                    const float a = 1.0f - bb;
+                    res.x = a * A.x + bb * Bv.x;
+                    res.y = a * A.y + bb * Bv.y;
+                    res.z = a * A.z + bb * Bv.z;
+                    res.w = 0.f;
+                    if (meta.loop == PARC_LOOP_WRAP) { // _calc_loop_offset :440
+                        float t = mt;
+#pragma unroll
+                        for (int q = 0; q < PARC_MAX_TAR_STEPS; ++q) t = (r - 2 == q) ? mt + P.tstep[q] : t;
+                        const float ph = floorf(t / meta.length);
+                        res.x = res.x + ph * meta.dx; res.y = res.y + ph * meta.dy; res.z = res.z + ph * meta.dz;
+                    }
+                    res.x = res.x + offx; // _move_to_motion_terrain dm_env.py:554
+                    res.y = res.y + offy;
+                } else if (i < B) {
+                    res = slerp(A, Bv, bb);
+                }
+            }
+            s_q[r][i] = res;
+            if (r == 1) { // optional mirrors of the reference's ref_* tensors
+                if (i == 0 && P.buf.ref_root_rot) *(float4 *)(P.buf.ref_root_rot + 4 * (size_t)e) = res;
+                if (i >= 1 && i < B && P.buf.ref_joint_rot) *(float4 *)(P.buf.ref_joint_rot + 4 * ((size_t)e * J + i - 1)) = res;
+                if (i == 15 && P.buf.ref_root_pos) {
+                    float *o = P.buf.ref_root_pos + 3 * (size_t)e;
+                    o[0] = res.x; o[1] = res.y; o[2] = res.z;
+                }
+            } else { // observation pieces (ig_char_env.py:582, mgdm_dm_util.py:405)
+                const int base = r == 0 ? 0 : P.off_tar + (r - 2) * P.tar_w;
+                if (i < B) {
+                    const Q4 qq = i == 0 ? quat_mul(hinv, res) : res;
+                    float tn[6];
+                    quat_to_tan_norm(qq, tn);
+                    const int o = r == 0 ? (i == 0 ? 0 : 12 + 6 * (i - 1)) : base + 3 + 6 * i;
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) s_obs[o + c] = tn[c];
+                } else if (i == 15 && r >= 2) {
+                    const V3 rpo = quat_rotate(hinv, mk3(res.x - root_pos.x, res.y - root_pos.y, res.z - root_pos.z));
+                    s_obs[base + 0] = rpo.x; s_obs[base + 1] = rpo.y; s_obs[base + 2] = rpo.z;
+                    s_rpo[r] = make_float4(rpo.x, rpo.y, rpo.z, 0.f);
+                }
+            }
+        }
+    }
+    // ---- contacts of the 1+S samples and the velocity block of sample 0 ---------------------------------
+    if (lane < 4 * (1 + S)) {
+        const int s = lane >> 2, c = lane & 3;
+        const float b = cblend, a = 1.0f - b;
+        const float v[4] = {a * cA.x + b * cB.x, a * cA.y + b * cB.y, a * cA.z + b * cB.z, a * cA.w + b * cB.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int bd = 4 * c + k;
+            if (bd < B) {
+                if (s == 0) {
+                    s_refct[bd] = v[k];
+                    if (P.buf.ref_contacts) P.buf.ref_contacts[(size_t)e * B + bd] = v[k];
                 } else {
-                    const int r = row + 1;
-                    const float4 kp = s_bp[r][b], tr = s_q[r][15], rpo = s_rpo[r];
-                    const V3 rl = quat_rotate(hinv, mk3(kp.x - tr.x, kp.y - tr.y, kp.z - tr.z));
-                    const int o = P.off_tar + (r - 2) * P.tar_w + 3 + 6 * B + 3 * kk;
-                    s_obs[o] = rl.x + rpo.x; s_obs[o + 1] = rl.y + rpo.y; s_obs[o + 2] = rl.z + rpo.z;
+                    orow[P.off_tarc + (s - 1) * B + bd] = v[k];
                 }
             }
         }
-
-        // ---- height rays (mgdm_dm_util.py:128-145; terrain_util.py:146-156) ---------------------
-        {
-            const float gx = root_pos.x + eox, gy = root_pos.y + eoy, gz = root_pos.z + eoz; // ig_parkour_env.py:522
-            const int tr = P.tile_r, TW = 2 * tr + 1;
-            const int ox = cell_index(gx, P.min_x, P.dx) - tr, oy = cell_index(gy, P.min_y, P.dy) - tr;
-            for (int idx = lane; idx < TW * TW; idx += 64) {
-                const int a = idx / TW, bq = idx - a * TW;
-                const int cx = min(max(ox + a, 0), P.X - 1), cy = min(max(oy + bq, 0), P.Y - 1);
-                s_tile[idx] = P.hf[(size_t)cx * P.Y + cy];
-            }
-            __syncthreads();
-            const float ch = cosf(heading), sh = sinf(heading);
-            for (int r = lane; r < P.R; r += 64) {
-                const float rx = P.ray_points[2 * r], ry = P.ray_points[2 * r + 1];
-                const float px = (rx * ch - ry * sh) + gx; // rotate_2d_vec torch_util.py:651
-                const float py = (rx * sh + ry * ch) + gy;
-                const int ix = cell_index(px, P.min_x, P.dx), iy = cell_index(py, P.min_y, P.dy);
-                const int a = ix - ox, bq = iy - oy;
-                float h;
-                if (a >= 0 && a < TW && bq >= 0 && bq < TW) {
-                    h = s_tile[a * TW + bq];
-                } else { // outside the staged tile (cannot happen for the default fan; kept for safety)
-                    const int cx = min(max(ix, 0), P.X - 1), cy = min(max(iy, 0), P.Y - 1);
-                    h = P.hf[(size_t)cx * P.Y + cy];
-                }
-                h = h - gz;
-                h = fminf(fmaxf(h, P.min_obs_h), P.max_obs_h);
-                s_obs[P.off_hf + r] = h;
-                if (P.buf.ray_hfs) P.buf.ray_hfs[(size_t)e * P.R + r] = h;
-            }
+    } else if (lane >= 32 && lane < 32 + nvel) {
+        const int c = lane - 32;
+        s_refvel[c] = cA;
+        if (c == 0 && P.buf.ref_root_vel) { float *o = P.buf.ref_root_vel + 3 * (size_t)e; o[0] = cA.x; o[1] = cA.y; o[2] = cA.z; }
+        if (c == 1 && P.buf.ref_root_ang_vel) { float *o = P.buf.ref_root_ang_vel + 3 * (size_t)e; o[0] = cA.x; o[1] = cA.y; o[2] = cA.z; }
+        if (c >= 2 && P.buf.ref_dof_vel) {
+            const float vv[4] = {cA.x, cA.y, cA.z, cA.w};
+            for (int k = 0; k < 4; ++k) { const int d = 4 * (c - 2) + k; if (d < D) P.buf.ref_dof_vel[(size_t)e * D + d] = vv[k]; }
         }
+    }
+    __syncthreads();
+    STAMP(3);
 
-        if (MODE == MODE_STEP) {
-            // ---- reward terms (mgdm_dm_util.py:270-333, 498-518) ------------------------------
-            if (lane < P.J) { // pose: angle of ref (x) conj(char) per joint
-                const float d = quat_diff_angle(s_q[0][1 + lane], s_q[1][1 + lane]);
-                s_red[0][lane] = s_tab.joint_err_w[lane] * d * d;
+    // ================= FK: row k = lane>>3, root-to-leaf chain c = lane&7 (kin_char_model.py:617-649) =================
+    {
+        const int k = lane >> 3, c = lane & 7;
+        if (k < 2 + S) {
+            Q4 prot = s_q[k][0];
+            const float4 pp = s_q[k][15];
+            V3 ppos = mk3(pp.x, pp.y, pp.z);
+            if (c == 0 && k < 2) {
+                s_fk[k * 16] = make_float4(ppos.x, ppos.y, ppos.z, 0.f);
+                if (P.tracking) s_br[k][0] = prot;
             }
-            if (lane < D) {
-                const float v = ((const float *)s_refvel)[8 + lane] - s_cdofv[lane];
-                s_red[1][lane] = s_tab.dof_err_w[lane] * v * v;
-            }
-            if (lane >= 48 && lane < 48 + K) { // key positions: simulator bodies vs reference FK (ig_parkour_env.py:987)
-                const int b = s_tab.key_ids[lane - 48];
-                const float4 kp = s_cbp[b], tk = s_bp[1][b], trp = s_q[1][15];
-                const float dx = (tk.x - trp.x) - (kp.x - root_pos.x);
-                const float dy = (tk.y - trp.y) - (kp.y - root_pos.y);
-                const float dz = (tk.z - trp.z) - (kp.z - root_pos.z);
-                s_red[2][lane - 48] = dx * dx + dy * dy + dz * dz;
-            }
-            if (lane >= 32 && lane < 32 + B) { // contact term
-                const int b = lane - 32;
-                const float tar = s_refct[b], f = s_cfn[b];
-                float cr = -(1.0f - tar) * f;
-                cr = cr + tar * f;
-                s_red[3][b] = s_tab.contact_w[b] * cr;
-            }
-            // ---- early termination (mgdm_dm_util.py:335-402) ------------------------------------
-            bool bad = false;
-            if (lane >= 1 && lane < B) {
-                const float4 bp = s_cbp[lane], b0 = s_cbp[0], tp = s_bp[1][lane], t0 = s_bp[1][0];
-                const float dx = (tp.x - t0.x) - (bp.x - b0.x);
-                const float dy = (tp.y - t0.y) - (bp.y - b0.y);
-                const float dz = (tp.z - t0.z) - (bp.z - b0.z);
-                const float lim = s_tab.pose_term_dist[lane - 1];
-                bad = (dx * dx + dy * dy + dz * dz) > lim * lim;
-            }
-            const bool pose_fail_any = __ballot(bad) != 0ull;
-            __syncthreads();
-
-            if (lane == 0) {
-                float pose_err = 0.f, vel_err = 0.f, key_err = 0.f, csum = 0.f;
-                for (int j = 0; j < P.J; ++j) pose_err = pose_err + s_red[0][j];
-                for (int d = 0; d < D; ++d) vel_err = vel_err + s_red[1][d];
-                for (int k = 0; k < K; ++k) key_err = key_err + s_red[2][k];
-                for (int b = 0; b < B; ++b) csum = csum + s_red[3][b];
-                const float4 trp = s_q[1][15];
-                const Q4 trr = s_q[1][0];
-                float rdx = trp.x - root_pos.x, rdy = trp.y - root_pos.y, rdz = trp.z - root_pos.z;
-                if (!P.track_root) { rdx = 0.f; rdy = 0.f; }
-                if (!P.track_root_h) rdz = 0.f;
-                const float root_pos_err = rdx * rdx + rdy * rdy + rdz * rdz;
-                const float *rv = P.buf.char_root_vel + 3 * (size_t)e, *rav = P.buf.char_root_ang_vel + 3 * (size_t)e;
-                const float4 tv = s_refvel[0], tav = s_refvel[1];
-                float rre = quat_diff_angle(root_rot, trr);
-                const float root_rot_angle = rre;
-                rre = rre * rre;
-                float d0 = tv.x - rv[0], d1 = tv.y - rv[1], d2 = tv.z - rv[2];
-                const float rve = d0 * d0 + d1 * d1 + d2 * d2;
-                d0 = tav.x - rav[0]; d1 = tav.y - rav[1]; d2 = tav.z - rav[2];
-                const float rave = d0 * d0 + d1 * d1 + d2 * d2;
-                const float pose_r = expf(-0.25f * pose_err);
-                const float vel_r = expf(-0.01f * vel_err);
-                const float root_pose_r = expf(-5.0f * (root_pos_err + 0.1f * rre));
-                const float root_vel_r = expf(-1.0f * (rve + 0.1f * rave));
-                const float key_pos_r = expf(-10.0f * key_err);
-                float rew = P.pose_w * pose_r + P.vel_w * vel_r + P.root_pos_w * root_pose_r + P.root_vel_w * root_vel_r +
-                            P.key_pos_w * key_pos_r;
-                const float contact_pen = csum / (float)B; // torch.mean over bodies (ig_parkour_env.py:1033)
-                rew = rew + contact_pen;
-                P.buf.reward[e] = rew;
-                if (P.buf.reward_terms) {
-                    float *rt = P.buf.reward_terms;
-                    const size_t N = (size_t)P.N;
-                    rt[0 * N + e] = pose_r; rt[1 * N + e] = vel_r; rt[2 * N + e] = root_pose_r; rt[3 * N + e] = root_vel_r;
-                    rt[4 * N + e] = key_pos_r; rt[5 * N + e] = contact_pen; rt[6 * N + e] = rew;
-                }
-                // done (compute_done + DeepMimicEnv.update_done dm_env.py:628-665)
-                int done = PARC_DONE_NULL;
-                if (time >= P.episode_length) done = PARC_DONE_TIME;
-                if (P.early_term) {
-                    bool failed = false;
-                    if (P.pose_term) {
-                        bool pf = pose_fail_any;
-                        if (P.track_root) {
-                            const float4 b0 = s_cbp[0], t0 = s_bp[1][0];
-                            const float ex = b0.x - t0.x, ey = b0.y - t0.y, ez = b0.z - t0.z;
-                            pf = pf || (ex * ex + ey * ey + ez * ez) > P.root_pos_term_sq;
-                            pf = pf || fabsf(root_rot_angle) > P.root_rot_term;
-                        }
-                        failed = pf;
-                    }
-                    if (!(time > 1e-5f)) failed = false;
-                    if (failed) done = PARC_DONE_FAIL;
-                }
-                const bool motion_end = (mt >= meta.length) && (meta.loop != PARC_LOOP_WRAP);
-                unsigned char code = 0;
-                if (done != PARC_DONE_NULL || motion_end) code = (done == PARC_DONE_FAIL) ? 1 : 2;
-                if (motion_end) done = PARC_DONE_FAIL;
-                P.buf.done[e] = done;
-                P.ema_code[e] = code;
-                if (code) { atomicAdd(P.chunk_count + (e >> 10), 1); atomicAdd(P.motion_done_count + mid, 1); }
-                P.buf.timestep[e] = ts;
-                if (P.buf.time) P.buf.time[e] = time;
-            }
-
-            // optional outputs: ref body positions / dof positions, character FK bodies, tracking error
-            if (P.buf.ref_body_pos && lane < B) {
-                float *o = P.buf.ref_body_pos + 3 * ((size_t)e * B + lane);
-                const float4 v = s_bp[1][lane];
-                o[0] = v.x; o[1] = v.y; o[2] = v.z;
-            }
-            if (P.buf.ref_dof_pos && lane >= 1 && lane < B) { // kin_char_model.py:601
-                const int ty = s_tab.jtype[lane];
-                float out3[3] = {0.f, 0.f, 0.f};
-                joint_rot_to_dof(ty, s_tab.axis[lane], s_q[1][lane], out3);
-                const int nd = ty == PARC_JOINT_HINGE ? 1 : (ty == PARC_JOINT_SPHERICAL ? 3 : 0);
-                for (int k = 0; k < nd; ++k) P.buf.ref_dof_pos[(size_t)e * D + s_tab.dof_idx[lane] + k] = out3[k];
-            }
-            if (P.tracking && P.buf.tracking_error) { // mgdm_dm_util.py:521-553
-                if (lane < B) {
-                    s_red[0][lane] = fabsf(quat_diff_angle(s_br[0][lane], s_br[1][lane]));
-                    const float4 cb = s_bp[0][lane], rb = s_bp[1][lane], trp = s_q[1][15];
-                    const V3 dd = mk3((rb.x - trp.x) - (cb.x - root_pos.x), (rb.y - trp.y) - (cb.y - root_pos.y),
-                                      (rb.z - trp.z) - (cb.z - root_pos.z));
-                    s_red[1][lane] = norm3(dd);
-                }
-                if (lane < D) s_red[2][lane] = fabsf(((const float *)s_refvel)[8 + lane] - s_cdofv[lane]);
-                __syncthreads();
-                if (lane == 0) {
-                    float pe = 0.f, bpe = 0.f, dve = 0.f;
-                    for (int b = 0; b < B; ++b) { pe = pe + s_red[0][b]; bpe = bpe + s_red[1][b]; }
-                    for (int d = 0; d < D; ++d) dve = dve + s_red[2][d];
-                    const float4 trp = s_q[1][15];
-                    const float *rv = P.buf.char_root_vel + 3 * (size_t)e, *rav = P.buf.char_root_ang_vel + 3 * (size_t)e;
-                    const float4 tv = s_refvel[0], tav = s_refvel[1];
-                    float *te = P.buf.tracking_error + 7 * (size_t)e;
-                    te[0] = norm3(mk3(trp.x - root_pos.x, trp.y - root_pos.y, trp.z - root_pos.z));
-                    te[1] = fabsf(quat_diff_angle(root_rot, s_q[1][0]));
-                    te[2] = bpe / (float)B;
-                    te[3] = pe / (float)B;
-                    te[4] = dve / (float)D;
-                    te[5] = (fabsf(tv.x - rv[0]) + fabsf(tv.y - rv[1]) + fabsf(tv.z - rv[2])) / 3.f;
-                    te[6] = (fabsf(tav.x - rav[0]) + fabsf(tav.y - rav[1]) + fabsf(tav.z - rav[2])) / 3.f;
+#pragma unroll 1
+            for (int d = 0; d < PARC_MAX_FK_DEPTH; ++d) {
+                const int b = s_tab.fk_paths[c][d];
+                if (b < 0) break;
+                const V3 wt = quat_rotate(prot, mk3(s_tab.lt[b][0], s_tab.lt[b][1], s_tab.lt[b][2]));
+                ppos = mk3(ppos.x + wt.x, ppos.y + wt.y, ppos.z + wt.z);
+                const Q4 lr = mk4(s_tab.lr[b][0], s_tab.lr[b][1], s_tab.lr[b][2], s_tab.lr[b][3]);
+                prot = quat_mul(prot, quat_mul(lr, s_q[k][b]));
+                if (k < 2) {
+                    s_fk[k * 16 + b] = make_float4(ppos.x, ppos.y, ppos.z, 0.f);
+                    if (P.tracking) s_br[k][b] = prot;
+                } else {
+                    const int slot = s_tab.key_slot[b];
+                    if (slot >= 0) s_fk[32 + (k - 2) * 8 + slot] = make_float4(ppos.x, ppos.y, ppos.z, 0.f);
                 }
             }
         }
-        if (P.body_pos_from_fk && P.buf.char_body_pos && lane < B) {
-            float *o = P.buf.char_body_pos + 3 * ((size_t)e * B + lane);
-            const float4 v = s_bp[0][lane];
+    }
+    __syncthreads();
+    if (P.body_pos_from_fk && lane < B) s_cbp[lane] = s_fk[lane];
+    STAMP(4);
+
+    // ================= key-body observations (ig_char_env.py:603-617, mgdm_dm_util.py:415-440) =================
+    if (lane < 8 * (1 + S)) {
+        const int row = lane >> 3, kk = lane & 7; // row 0 = char, 1.. = target rows 2..
+        if (kk < K) {
+            if (row == 0) {
+                const float4 kp = s_fk[s_tab.key_ids[kk]];
+                const V3 rl = quat_rotate(hinv, mk3(kp.x - root_pos.x, kp.y - root_pos.y, kp.z - root_pos.z));
+                const int o = P.off_key + 3 * kk;
+                s_obs[o] = rl.x; s_obs[o + 1] = rl.y; s_obs[o + 2] = rl.z;
+            } else {
+                const int r = row + 1;
+                const float4 kp = s_fk[32 + (r - 2) * 8 + s_tab.key_slot[s_tab.key_ids[kk]]], trp = s_q[r][15], rpo = s_rpo[r];
+                const V3 rl = quat_rotate(hinv, mk3(kp.x - trp.x, kp.y - trp.y, kp.z - trp.z));
+                const int o = P.off_tar + (r - 2) * P.tar_w + 3 + 6 * B + 3 * kk;
+                s_obs[o] = rl.x + rpo.x; s_obs[o + 1] = rl.y + rpo.y; s_obs[o + 2] = rl.z + rpo.z;
+            }
+        }
+    }
+    STAMP(5);
+
+    if (MODE == MODE_STEP) {
+        __syncthreads(); // s_cbp
+        // ---- reward terms, one per lane (mgdm_dm_util.py:270-333, 498-518), reduced with wave butterflies ----
+        float t_pose = 0.f, t_vel = 0.f, t_key = 0.f, t_con = 0.f;
+        if (lane < J) { // pose: angle of ref (x) conj(char) per joint
+            const float d = quat_diff_angle(s_q[0][1 + lane], s_q[1][1 + lane]);
+            t_pose = T->joint_err_w[lane] * d * d;
+        }
+        if (lane < D) {
+            const float v = ((const float *)s_refvel)[8 + lane] - s_cdofv[lane];
+            t_vel = T->dof_err_w[lane] * v * v;
+        }
+        if (lane >= 48 && lane < 48 + K) { // key positions: simulator bodies vs reference FK (ig_parkour_env.py:987)
+            const int b = s_tab.key_ids[lane - 48];
+            const float4 kp = s_cbp[b], tk = s_fk[16 + b], trp = s_q[1][15];
+            const float dx = (tk.x - trp.x) - (kp.x - root_pos.x);
+            const float dy = (tk.y - trp.y) - (kp.y - root_pos.y);
+            const float dz = (tk.z - trp.z) - (kp.z - root_pos.z);
+            t_key = dx * dx + dy * dy + dz * dz;
+        }
+        if (lane >= 32 && lane < 32 + B) { // contact term
+            const int b = lane - 32;
+            const float tar = s_refct[b], f = s_cfn[b];
+            float cr = -(1.0f - tar) * f;
+            cr = cr + tar * f;
+            t_con = T->contact_w[b] * cr;
+        }
+        // ---- early termination (mgdm_dm_util.py:335-402) ----
+        bool bad = false;
+        if (lane >= 1 && lane < B) {
+            const float4 bp = s_cbp[lane], b0 = s_cbp[0], tp = s_fk[16 + lane], t0 = s_fk[16];
+            const float dx = (tp.x - t0.x) - (bp.x - b0.x);
+            const float dy = (tp.y - t0.y) - (bp.y - b0.y);
+            const float dz = (tp.z - t0.z) - (bp.z - b0.z);
+            const float lim = T->pose_term_dist[lane - 1];
+            bad = (dx * dx + dy * dy + dz * dz) > lim * lim;
+        }
+        const bool pose_fail_any = __ballot(bad) != 0ull;
+        const float pose_err = wave_sum(t_pose), vel_err = wave_sum(t_vel), key_err = wave_sum(t_key), csum = wave_sum(t_con);
+
+        // uniform tail: every lane computes the same scalars (no divergence), lane 0 stores
+        const float4 trp = s_q[1][15];
+        const Q4 trr = s_q[1][0];
+        float rdx = trp.x - root_pos.x, rdy = trp.y - root_pos.y, rdz = trp.z - root_pos.z;
+        if (!P.track_root) { rdx = 0.f; rdy = 0.f; }
+        if (!P.track_root_h) rdz = 0.f;
+        const float root_pos_err = rdx * rdx + rdy * rdy + rdz * rdz;
+        const float4 tv = s_refvel[0], tav = s_refvel[1];
+        const float rvx = __shfl(aux0, 30, 64), rvy = __shfl(aux1, 30, 64), rvz = __shfl(aux2, 30, 64);
+        const float rax = __shfl(aux0, 31, 64), ray_ = __shfl(aux1, 31, 64), raz = __shfl(aux2, 31, 64);
+        const float root_rot_angle = quat_diff_angle(root_rot, trr);
+        const float rre = root_rot_angle * root_rot_angle;
+        float d0 = tv.x - rvx, d1 = tv.y - rvy, d2 = tv.z - rvz;
+        const float rve = d0 * d0 + d1 * d1 + d2 * d2;
+        d0 = tav.x - rax; d1 = tav.y - ray_; d2 = tav.z - raz;
+        const float rave = d0 * d0 + d1 * d1 + d2 * d2;
+        const float pose_r = expf(-0.25f * pose_err);
+        const float vel_r = expf(-0.01f * vel_err);
+        const float root_pose_r = expf(-5.0f * (root_pos_err + 0.1f * rre));
+        const float root_vel_r = expf(-1.0f * (rve + 0.1f * rave));
+        const float key_pos_r = expf(-10.0f * key_err);
+        float rew = P.pose_w * pose_r + P.vel_w * vel_r + P.root_pos_w * root_pose_r + P.root_vel_w * root_vel_r + P.key_pos_w * key_pos_r;
+        const float contact_pen = csum / (float)B; // torch.mean over bodies (ig_parkour_env.py:1033)
+        rew = rew + contact_pen;
+        // done (compute_done + DeepMimicEnv.update_done dm_env.py:628-665)
+        int done = PARC_DONE_NULL;
+        if (time >= P.episode_length) done = PARC_DONE_TIME;
+        if (P.early_term) {
+            bool failed = false;
+            if (P.pose_term) {
+                bool pf = pose_fail_any;
+                if (P.track_root) {
+                    const float4 b0 = s_cbp[0], t0 = s_fk[16];
+                    const float ex = b0.x - t0.x, ey = b0.y - t0.y, ez = b0.z - t0.z;
+                    pf = pf || (ex * ex + ey * ey + ez * ez) > P.root_pos_term_sq;
+                    pf = pf || fabsf(root_rot_angle) > P.root_rot_term;
+                }
+                failed = pf;
+            }
+            if (!(time > 1e-5f)) failed = false;
+            if (failed) done = PARC_DONE_FAIL;
+        }
+        const bool motion_end = (mt >= meta.length) && (meta.loop != PARC_LOOP_WRAP);
+        unsigned char code = 0;
+        if (done != PARC_DONE_NULL || motion_end) code = (done == PARC_DONE_FAIL) ? 1 : 2;
+        if (motion_end) done = PARC_DONE_FAIL;
+        if (lane == 0) {
+            P.buf.reward[e] = rew;
+            P.buf.done[e] = done;
+            P.ema_code[e] = code;
+            P.buf.timestep[e] = ts;
+            if (P.buf.time) P.buf.time[e] = time;
+        }
+        if (P.buf.reward_terms && lane < 7) {
+            const float vals[7] = {pose_r, vel_r, root_pose_r, root_vel_r, key_pos_r, contact_pen, rew};
+            float v = vals[0];
+#pragma unroll
+            for (int q = 1; q < 7; ++q) v = lane == q ? vals[q] : v;
+            P.buf.reward_terms[(size_t)lane * P.N + e] = v;
+        }
+
+        // optional outputs: ref body positions / dof positions, tracking error
+        if (P.buf.ref_body_pos && lane < B) {
+            float *o = P.buf.ref_body_pos + 3 * ((size_t)e * B + lane);
+            const float4 v = s_fk[16 + lane];
             o[0] = v.x; o[1] = v.y; o[2] = v.z;
         }
-        __syncthreads();
-
-        // ---- stream the observation row out: 16 bytes per lane per store -------------------------
-        {
-            float *orow = P.buf.obs + (size_t)e * P.obs_dim;
-            if ((P.obs_dim & 3) == 0) {
-                const float4 *src = (const float4 *)s_obs;
-                float4 *dst = (float4 *)orow;
-                for (int i = lane; i < (P.obs_dim >> 2); i += 64) dst[i] = src[i];
-            } else {
-                for (int i = lane; i < P.obs_dim; i += 64) orow[i] = s_obs[i];
+        if (P.buf.ref_dof_pos && lane >= 1 && lane < B) { // kin_char_model.py:601
+            const int ty = s_tab.jtype[lane];
+            float out3[3] = {0.f, 0.f, 0.f};
+            joint_rot_to_dof(ty, s_tab.axis[lane], s_q[1][lane], out3);
+            const int nd = ty == PARC_JOINT_HINGE ? 1 : (ty == PARC_JOINT_SPHERICAL ? 3 : 0);
+            for (int k = 0; k < nd; ++k) P.buf.ref_dof_pos[(size_t)e * D + s_tab.dof_idx[lane] + k] = out3[k];
+        }
+        if (P.tracking && P.buf.tracking_error) { // mgdm_dm_util.py:521-553
+            float e_rot = 0.f, e_pos = 0.f, e_dv = 0.f;
+            if (lane < B) {
+                e_rot = fabsf(quat_diff_angle(s_br[0][lane], s_br[1][lane]));
+                const float4 cb = s_fk[lane], rb = s_fk[16 + lane];
+                e_pos = norm3(mk3((rb.x - trp.x) - (cb.x - root_pos.x), (rb.y - trp.y) - (cb.y - root_pos.y), (rb.z - trp.z) - (cb.z - root_pos.z)));
+            }
+            if (lane < D) e_dv = fabsf(((const float *)s_refvel)[8 + lane] - s_cdofv[lane]);
+            const float pe = wave_sum(e_rot), bpe = wave_sum(e_pos), dve = wave_sum(e_dv);
+            if (lane == 0) {
+                float *te = P.buf.tracking_error + 7 * (size_t)e;
+                te[0] = norm3(mk3(trp.x - root_pos.x, trp.y - root_pos.y, trp.z - root_pos.z));
+                te[1] = fabsf(root_rot_angle);
+                te[2] = bpe / (float)B;
+                te[3] = pe / (float)B;
+                te[4] = dve / (float)D;
+                te[5] = (fabsf(tv.x - rvx) + fabsf(tv.y - rvy) + fabsf(tv.z - rvz)) / 3.f;
+                te[6] = (fabsf(tav.x - rax) + fabsf(tav.y - ray_) + fabsf(tav.z - raz)) / 3.f;
             }
         }
-        __syncthreads();
     }
+    if (P.body_pos_from_fk && P.buf.char_body_pos && lane < B) {
+        float *o = P.buf.char_body_pos + 3 * ((size_t)e * B + lane);
+        const float4 v = s_fk[lane];
+        o[0] = v.x; o[1] = v.y; o[2] = v.z;
+    }
+    __syncthreads();
+    STAMP(6);
+
+    // ================= stream the staged observation prefix out: 16 bytes per lane per store =================
+    {
+        const int nst = P.off_tarc; // [0, off_tarc) staged; contacts and rays were stored directly
+        if ((P.obs_dim & 3) == 0) {
+            const float4 *src = (const float4 *)s_obs;
+            float4 *dst = (float4 *)orow;
+            const int n4 = nst >> 2;
+            for (int i = lane; i < n4; i += 64) dst[i] = src[i];
+            for (int i = 4 * n4 + lane; i < nst; i += 64) orow[i] = s_obs[i];
+        } else {
+            for (int i = lane; i < nst; i += 64) orow[i] = s_obs[i];
+        }
+    }
+    STAMP(7);
+#ifdef PARC_STAMPS
+    __syncthreads();
+    if (lane < 7 && P.stamp_out) P.stamp_out[(size_t)e * 8 + lane] = (unsigned)(s_stamp[lane + 1] - s_stamp[lane]);
+    if (lane == 7 && P.stamp_out) P.stamp_out[(size_t)e * 8 + 7] = 0;
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -558,14 +686,28 @@ __global__ __launch_bounds__(64) void k_env_post(const StepParams P, const int64
 //                   f <- f*(1-w)+w (FAIL) / f <- f*(1-w) (TIME, SUCC, motion end) in that order.
 // The compacted list doubles as the env-id list of parc_env_reset_done (no nonzero(), no host sync).
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int nonzero_bytes(unsigned v) {
+    return ((v & 0xffu) != 0) + ((v & 0xff00u) != 0) + ((v & 0xff0000u) != 0) + ((v & 0xff000000u) != 0);
+}
+
+// Block b owns envs [1024 b, 1024 b + 1024).  Its base offset = number of finished envs before it, which it
+// counts itself from the (1 byte per env) code array: no atomics in the step kernel, no second launch.
 __global__ __launch_bounds__(1024) void k_done_scatter(const unsigned char *__restrict__ ema_code, const int *__restrict__ motion_ids,
-                                                       const int *__restrict__ chunk_count, int nchunks, int N, int *done_list,
-                                                       int *done_key, int *reset_count) {
+                                                       int N, int *done_list, int *done_key, int *reset_count) {
     __shared__ int s_base, s_wave[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.x;
     if (tid == 0) s_base = 0;
     __syncthreads();
-    if (tid < b && tid < nchunks) atomicAdd(&s_base, chunk_count[tid]);
+    {
+        const uint4 *src = (const uint4 *)ema_code; // hipMalloc'd: 16-byte aligned; 1024 b bytes = 64 b uint4
+        int c = 0;
+        for (int i = tid; i < 64 * b; i += 1024) {
+            const uint4 v = src[i];
+            c += nonzero_bytes(v.x) + nonzero_bytes(v.y) + nonzero_bytes(v.z) + nonzero_bytes(v.w);
+        }
+        for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off, 64);
+        if (lane == 0 && c) atomicAdd(&s_base, c);
+    }
     const int e = b * 1024 + tid;
     const unsigned char code = e < N ? ema_code[e] : 0;
     const unsigned long long mask = __ballot(code != 0);
@@ -582,34 +724,32 @@ __global__ __launch_bounds__(1024) void k_done_scatter(const unsigned char *__re
     if (b == (int)gridDim.x - 1 && tid == 0) *reset_count = s_base + total;
 }
 
+// One wave per motion: walk the env-ordered list 64 entries at a time, apply the chain in order.
 __global__ __launch_bounds__(256) void k_fail_rate_ema(const int *__restrict__ done_key, const int *__restrict__ reset_count,
-                                                       int *motion_done_count, int *chunk_count, int nchunks, float *fail_rates,
-                                                       int M, float w) {
+                                                       float *fail_rates, int M, float w) {
     const int lane = threadIdx.x & 63;
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (blockIdx.x == 0)
-        for (int i = threadIdx.x; i < nchunks; i += 256) chunk_count[i] = 0; // consumed by k_done_scatter
     if (m >= M) return;
-    const int c = motion_done_count[m];
-    if (c == 0) return;
     const int k = *reset_count;
+    if (k == 0) return;
     const float keep = (float)(1.0 - (double)w);
     float f = fail_rates[m];
-    int seen = 0;
-    for (int base = 0; base < k && seen < c; base += 64) {
+    bool any = false;
+    for (int base = 0; base < k; base += 64) {
         const int i = base + lane;
         const int v = i < k ? done_key[i] : -2;
         const bool match = (v >> 1) == m;
         unsigned long long mask = __ballot(match);
+        if (!mask) continue;
+        any = true;
         const unsigned long long failmask = __ballot(match && (v & 1));
-        seen += __popcll(mask);
         while (mask) {
             const int bit = __ffsll((long long)mask) - 1;
             f = ((failmask >> bit) & 1ull) ? (f * keep + w) : (f * keep);
             mask &= mask - 1ull;
         }
     }
-    if (lane == 0) { fail_rates[m] = f; motion_done_count[m] = 0; }
+    if (lane == 0 && any) fail_rates[m] = f;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -663,16 +803,16 @@ __global__ void k_motion_prep(const PrepParams P) {
     for (int j = 1; j < P.B; ++j) { // compute_dof_vel kin_char_model.py:661
         const float *a = P.joint_rot + 4 * ((size_t)f0 * P.J + j - 1), *b = a + 4 * P.J;
         const Q4 d = quat_normalize(quat_mul(quat_conj(mk4(a[0], a[1], a[2], a[3])), mk4(b[0], b[1], b[2], b[3])));
-        const int ty = T->jtype[j];
+        const int ty = T->h.jtype[j];
         if (ty == PARC_JOINT_HINGE) {
             V3 x = quat_to_exp_map(d);
             x = mk3(x.x / dt, x.y / dt, x.z / dt);
-            dv[T->dof_idx[j]] = T->axis[j][0] * x.x + T->axis[j][1] * x.y + T->axis[j][2] * x.z;
+            dv[T->h.dof_idx[j]] = T->h.axis[j][0] * x.x + T->h.axis[j][1] * x.y + T->h.axis[j][2] * x.z;
         } else if (ty == PARC_JOINT_SPHERICAL) {
             const V3 x = quat_to_exp_map(d);
-            dv[T->dof_idx[j] + 0] = x.x / dt;
-            dv[T->dof_idx[j] + 1] = x.y / dt;
-            dv[T->dof_idx[j] + 2] = x.z / dt;
+            dv[T->h.dof_idx[j] + 0] = x.x / dt;
+            dv[T->h.dof_idx[j] + 1] = x.y / dt;
+            dv[T->h.dof_idx[j] + 2] = x.z / dt;
         }
     }
 }
@@ -720,7 +860,7 @@ __global__ void k_dof_to_rot(const DevTables *T, const float *dof, float *jr, in
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     for (int j = 1; j < B; ++j)
-        *(float4 *)(jr + 4 * ((size_t)i * (B - 1) + j - 1)) = joint_dof_to_rot(T->jtype[j], T->axis[j], dof + (size_t)i * D + T->dof_idx[j]);
+        *(float4 *)(jr + 4 * ((size_t)i * (B - 1) + j - 1)) = joint_dof_to_rot(T->h.jtype[j], T->h.axis[j], dof + (size_t)i * D + T->h.dof_idx[j]);
 }
 
 __global__ void k_rot_to_dof(const DevTables *T, const float *jr, float *dof, int n, int B, int D) {
@@ -728,7 +868,7 @@ __global__ void k_rot_to_dof(const DevTables *T, const float *jr, float *dof, in
     if (i >= n) return;
     for (int d = 0; d < D; ++d) dof[(size_t)i * D + d] = 0.f;
     for (int j = 1; j < B; ++j)
-        joint_rot_to_dof(T->jtype[j], T->axis[j], *(const float4 *)(jr + 4 * ((size_t)i * (B - 1) + j - 1)), dof + (size_t)i * D + T->dof_idx[j]);
+        joint_rot_to_dof(T->h.jtype[j], T->h.axis[j], *(const float4 *)(jr + 4 * ((size_t)i * (B - 1) + j - 1)), dof + (size_t)i * D + T->h.dof_idx[j]);
 }
 
 __device__ void fk_thread(const DevTables *T, int B, V3 root_pos, Q4 root_rot, const float *jr, float *bp, float *br) {
@@ -736,11 +876,11 @@ __device__ void fk_thread(const DevTables *T, int B, V3 root_pos, Q4 root_rot, c
     V3 pos[PARC_MAX_BODIES];
     rot[0] = root_rot; pos[0] = root_pos;
     for (int j = 1; j < B; ++j) {
-        const int p = T->parent[j];
-        const V3 wt = quat_rotate(rot[p], mk3(T->lt[j][0], T->lt[j][1], T->lt[j][2]));
+        const int p = T->h.parent[j];
+        const V3 wt = quat_rotate(rot[p], mk3(T->h.lt[j][0], T->h.lt[j][1], T->h.lt[j][2]));
         pos[j] = mk3(pos[p].x + wt.x, pos[p].y + wt.y, pos[p].z + wt.z);
         const Q4 q = *(const float4 *)(jr + 4 * (j - 1));
-        rot[j] = quat_mul(rot[p], quat_mul(mk4(T->lr[j][0], T->lr[j][1], T->lr[j][2], T->lr[j][3]), q));
+        rot[j] = quat_mul(rot[p], quat_mul(mk4(T->h.lr[j][0], T->h.lr[j][1], T->h.lr[j][2], T->h.lr[j][3]), q));
     }
     for (int j = 0; j < B; ++j) {
         bp[3 * j] = pos[j].x; bp[3 * j + 1] = pos[j].y; bp[3 * j + 2] = pos[j].z;
@@ -795,7 +935,7 @@ __global__ void k_reset_with(const ResetParams P, const int64_t *env_ids, const 
     float *dof = P.buf.char_dof_pos + (size_t)e * D;
     for (int d = 0; d < D; ++d) dof[d] = 0.f;
     for (int j = 1; j < B; ++j)
-        joint_rot_to_dof(P.tables->jtype[j], P.tables->axis[j], *(const float4 *)(jr + 4 * (j - 1)), dof + P.tables->dof_idx[j]);
+        joint_rot_to_dof(P.tables->h.jtype[j], P.tables->h.axis[j], *(const float4 *)(jr + 4 * (j - 1)), dof + P.tables->h.dof_idx[j]);
     if (P.buf.ref_root_pos) { float *o = P.buf.ref_root_pos + 3 * (size_t)e; o[0] = rx; o[1] = ry; o[2] = rz; }
     if (P.buf.ref_root_rot) for (int c = 0; c < 4; ++c) P.buf.ref_root_rot[4 * (size_t)e + c] = P.buf.char_root_rot[4 * (size_t)e + c];
     if (P.buf.ref_root_vel) for (int c = 0; c < 3; ++c) P.buf.ref_root_vel[3 * (size_t)e + c] = P.buf.char_root_vel[3 * (size_t)e + c];
@@ -889,6 +1029,8 @@ struct ParcEnv {
     int64_t F = 0;
     bool bound = false, have_motions = false, have_terrain = false;
     StepParams sp;
+    StepParams *d_sp = nullptr;
+    float4 *d_prep = nullptr;
     DevTables h_tab;
     DevTables *d_tab = nullptr;
     float *d_ray = nullptr, *d_env_off = nullptr, *d_hf = nullptr, *d_motion_off = nullptr;
@@ -912,11 +1054,16 @@ extern "C" const char *parc_last_error(void) { return g_err.c_str(); }
 extern "C" int parc_abi_version(void) { return PARC_ABI_VERSION; }
 
 static void free_dev(ParcEnv *e) {
-    void *ptrs[] = {e->d_tab, e->d_ray, e->d_env_off, e->d_hf, e->d_motion_off, e->d_records, e->d_meta, e->d_weights, e->d_fail,
+    void *ptrs[] = {e->d_sp, e->d_prep, e->d_tab, e->d_ray, e->d_env_off, e->d_hf, e->d_motion_off, e->d_records, e->d_meta, e->d_weights, e->d_fail,
                     e->d_cdf, e->d_ema, e->d_done_list, e->d_done_key, e->d_chunk_count, e->d_motion_done, e->d_reset_count, e->d_tmp_mid, e->d_tmp_tid, e->d_tmp_t0, e->d_tmp_noise,
                     e->d_scratch_jr};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &ev : e->ev) if (ev) (void)hipEventDestroy(ev);
+}
+
+static int sync_params(ParcEnv *e) { // the kernels read StepParams through a device pointer
+    HIPCHK(hipMemcpy(e->d_sp, &e->sp, sizeof(StepParams), hipMemcpyHostToDevice));
+    return PARC_OK;
 }
 
 extern "C" int parc_env_create(const ParcEnvConfig *cfg, ParcEnv **out) {
@@ -950,22 +1097,23 @@ extern "C" int parc_env_create(const ParcEnvConfig *cfg, ParcEnv **out) {
 
     DevTables &t = e->h_tab;
     memset(&t, 0, sizeof(t));
-    for (int b = 0; b < 16; ++b) { t.parent[b] = -1; t.jtype[b] = PARC_JOINT_FIXED; }
+    for (int b = 0; b < 16; ++b) { t.h.parent[b] = -1; t.h.jtype[b] = PARC_JOINT_FIXED; t.h.key_slot[b] = -1; }
     for (int b = 0; b < B; ++b) {
-        t.parent[b] = m.parent[b]; t.jtype[b] = m.joint_type[b]; t.dof_idx[b] = m.dof_idx[b];
-        for (int c = 0; c < 3; ++c) { t.axis[b][c] = m.joint_axis[b][c]; t.lt[b][c] = m.local_translation[b][c]; }
-        for (int c = 0; c < 4; ++c) t.lr[b][c] = m.local_rotation[b][c];
+        t.h.parent[b] = m.parent[b]; t.h.jtype[b] = m.joint_type[b]; t.h.dof_idx[b] = m.dof_idx[b];
+        for (int c = 0; c < 3; ++c) { t.h.axis[b][c] = m.joint_axis[b][c]; t.h.lt[b][c] = m.local_translation[b][c]; }
+        for (int c = 0; c < 4; ++c) t.h.lr[b][c] = m.local_rotation[b][c];
     }
     for (int p = 0; p < PARC_MAX_FK_PATHS; ++p)
         for (int d = 0; d < PARC_MAX_FK_DEPTH; ++d) {
-            t.fk_paths[p][d] = m.fk_paths[p][d];
+            t.h.fk_paths[p][d] = m.fk_paths[p][d];
             if (m.fk_paths[p][d] >= B) { delete e; return fail(PARC_ERR_INVALID, "fk_paths entry out of range"); }
         }
     const float dt_f = (float)cfg->control_dt;
     for (int s = 0; s < S; ++s) t.tstep[s] = dt_f * (float)cfg->tar_obs_steps[s];
     for (int k = 0; k < K; ++k) {
         if (cfg->key_body_ids[k] < 0 || cfg->key_body_ids[k] >= B) { delete e; return fail(PARC_ERR_INVALID, "key body id out of range"); }
-        t.key_ids[k] = cfg->key_body_ids[k];
+        t.h.key_ids[k] = cfg->key_body_ids[k];
+        if (t.h.key_slot[cfg->key_body_ids[k]] < 0) t.h.key_slot[cfg->key_body_ids[k]] = k;
     }
     for (int j = 0; j < J; ++j) { t.joint_err_w[j] = cfg->joint_err_w[j]; t.pose_term_dist[j] = cfg->pose_termination_dist[j]; }
     for (int d = 0; d < D; ++d) t.dof_err_w[d] = cfg->dof_err_w[d];
@@ -984,6 +1132,7 @@ extern "C" int parc_env_create(const ParcEnvConfig *cfg, ParcEnv **out) {
     sp.off_hf = sp.off_cc + B;
     sp.obs_dim = sp.off_hf + R;
     e->obs_dim = sp.obs_dim;
+    for (int q = 0; q < S; ++q) sp.tstep[q] = dt_f * (float)cfg->tar_obs_steps[q];
     sp.dt_f = dt_f; sp.episode_length = cfg->episode_length; sp.min_obs_h = cfg->min_obs_h; sp.max_obs_h = cfg->max_obs_h;
     sp.pose_w = cfg->pose_w; sp.vel_w = cfg->vel_w; sp.root_pos_w = cfg->root_pos_w; sp.root_vel_w = cfg->root_vel_w; sp.key_pos_w = cfg->key_pos_w;
     sp.root_pos_term_sq = (float)((double)cfg->root_pos_termination_dist * (double)cfg->root_pos_termination_dist);
@@ -1000,9 +1149,11 @@ extern "C" int parc_env_create(const ParcEnvConfig *cfg, ParcEnv **out) {
     hipError_t r = hipSuccess;
     const size_t N = (size_t)e->N;
     if ((r = up((void **)&e->d_tab, &t, sizeof(t))) != hipSuccess ||
+        (r = up((void **)&e->d_sp, nullptr, sizeof(StepParams))) != hipSuccess ||
+        (r = up((void **)&e->d_prep, nullptr, sizeof(float4) * 16 * N)) != hipSuccess ||
         (r = up((void **)&e->d_ray, cfg->ray_points_host, sizeof(float) * 2 * R)) != hipSuccess ||
         (r = up((void **)&e->d_env_off, cfg->env_offsets_host, sizeof(float) * 3 * N)) != hipSuccess ||
-        (r = up((void **)&e->d_ema, nullptr, N)) != hipSuccess ||
+        (r = up((void **)&e->d_ema, nullptr, ((N + 1023) / 1024) * 1024)) != hipSuccess ||
         (r = up((void **)&e->d_done_list, nullptr, sizeof(int) * N)) != hipSuccess ||
         (r = up((void **)&e->d_done_key, nullptr, sizeof(int) * N)) != hipSuccess ||
         (r = up((void **)&e->d_chunk_count, nullptr, sizeof(int) * 1024)) != hipSuccess ||
@@ -1017,7 +1168,10 @@ extern "C" int parc_env_create(const ParcEnvConfig *cfg, ParcEnv **out) {
     }
     for (auto &ev : e->ev) (void)hipEventCreate(&ev);
     sp.tables = e->d_tab; sp.ray_points = e->d_ray; sp.env_offsets = e->d_env_off;
-    sp.ema_code = e->d_ema; sp.chunk_count = e->d_chunk_count;
+    sp.ema_code = e->d_ema; sp.prep = e->d_prep;
+#ifdef PARC_STAMPS
+    if (hipMalloc((void **)&sp.stamp_out, sizeof(unsigned) * 8 * N) != hipSuccess) sp.stamp_out = nullptr;
+#endif
     e->nchunks = (e->N + 1023) / 1024;
     if (e->nchunks > 1024) { free_dev(e); delete e; return fail(PARC_ERR_INVALID, "num_envs must be <= 1048576 per handle"); }
 
@@ -1102,8 +1256,8 @@ extern "C" int parc_env_load_motions(ParcEnv *e, const ParcMotionClips *c) {
     (void)hipFree(d_rp); (void)hipFree(d_rr); (void)hipFree(d_jr); (void)hipFree(d_fm);
     if (d_ct) (void)hipFree(d_ct);
     e->M = M; e->F = F; e->have_motions = true;
-    e->sp.M = M; e->sp.records = e->d_records; e->sp.meta = e->d_meta; e->sp.motion_done_count = e->d_motion_done;
-    return PARC_OK;
+    e->sp.M = M; e->sp.records = e->d_records; e->sp.meta = e->d_meta;
+    return sync_params(e);
 }
 
 extern "C" int parc_env_load_terrain(ParcEnv *e, const float *hf, int32_t X, int32_t Y, float min_x, float min_y, float dx, float dy,
@@ -1128,12 +1282,19 @@ extern "C" int parc_env_load_terrain(ParcEnv *e, const float *hf, int32_t X, int
     float rmax = 0.f;
     for (int r = 0; r < e->R; ++r) rmax = fmaxf(rmax, sqrtf(ray[2 * r] * ray[2 * r] + ray[2 * r + 1] * ray[2 * r + 1]));
     int tr = (int)ceilf(rmax / fminf(dx, dy) + 0.01f); // max |round(a+d)-round(a)| = ceil(|d|)
-    if (tr > 24) tr = 24; // larger fans fall back to direct gathers for the outer samples
+    if ((2 * tr + 1) * (2 * tr + 1) > TILE_MAX_CELLS) tr = -1; // fan too wide for the LDS tile: direct gathers
     sp.tile_r = tr;
-    const int obs_pad = (e->obs_dim + 3) & ~3;
-    e->lds_bytes = sizeof(float) * ((size_t)obs_pad + (size_t)(2 * tr + 1) * (2 * tr + 1));
+    if (tr >= 0) { // magic multiplier for idx / TW, verified for every cell of the tile
+        const unsigned TW = 2 * tr + 1;
+        const unsigned mul = (65536u + TW - 1) / TW;
+        for (unsigned idx = 0; idx < TW * TW; ++idx)
+            if (((idx * mul) >> 16) != idx / TW) return fail(PARC_ERR_INVALID, "internal: tile index multiplier");
+        sp.tile_mul = mul;
+    }
+    const int stage_pad = (sp.off_tarc + 3) & ~3;
+    e->lds_bytes = sizeof(float) * (size_t)stage_pad;
     e->have_terrain = true;
-    return PARC_OK;
+    return sync_params(e);
 }
 
 extern "C" int parc_env_bind_buffers(ParcEnv *e, const ParcEnvBuffers *b) {
@@ -1148,7 +1309,7 @@ extern "C" int parc_env_bind_buffers(ParcEnv *e, const ParcEnvBuffers *b) {
         return fail(PARC_ERR_INVALID, "quaternion buffers must be 16-byte aligned");
     e->sp.buf = *b;
     e->bound = true;
-    return PARC_OK;
+    return sync_params(e);
 }
 
 static int check_ready(ParcEnv *e) {
@@ -1158,10 +1319,10 @@ static int check_ready(ParcEnv *e) {
 }
 
 static int launch_curriculum(ParcEnv *e, hipStream_t st) {
-    hipLaunchKernelGGL(k_done_scatter, dim3(e->nchunks), dim3(1024), 0, st, e->d_ema, e->sp.buf.motion_ids, e->d_chunk_count, e->nchunks, e->N,
-                       e->d_done_list, e->d_done_key, e->d_reset_count);
-    hipLaunchKernelGGL(k_fail_rate_ema, dim3((e->M + 3) / 4), dim3(256), 0, st, e->d_done_key, e->d_reset_count, e->d_motion_done,
-                       e->d_chunk_count, e->nchunks, e->d_fail, e->M, e->cfg.fail_rate_ema_weight);
+    hipLaunchKernelGGL(k_done_scatter, dim3(e->nchunks), dim3(1024), 0, st, e->d_ema, e->sp.buf.motion_ids, e->N, e->d_done_list,
+                       e->d_done_key, e->d_reset_count);
+    hipLaunchKernelGGL(k_fail_rate_ema, dim3((e->M + 3) / 4), dim3(256), 0, st, e->d_done_key, e->d_reset_count, e->d_fail, e->M,
+                       e->cfg.fail_rate_ema_weight);
     HIPCHK(hipGetLastError());
     return PARC_OK;
 }
@@ -1169,9 +1330,10 @@ static int launch_curriculum(ParcEnv *e, hipStream_t st) {
 static int launch_post(ParcEnv *e, int mode, const int64_t *ids, int count, hipStream_t st, const int *ids32 = nullptr,
                        const int *count_dev = nullptr) {
     if (count <= 0) return PARC_OK;
-    const int grid = count < e->grid_waves ? count : e->grid_waves;
-    if (mode == MODE_STEP) hipLaunchKernelGGL(k_env_post<MODE_STEP>, dim3(grid), dim3(64), e->lds_bytes, st, e->sp, ids, ids32, count_dev, count);
-    else hipLaunchKernelGGL(k_env_post<MODE_OBS>, dim3(grid), dim3(64), e->lds_bytes, st, e->sp, ids, ids32, count_dev, count);
+    const int grid = count;
+    hipLaunchKernelGGL(k_env_prep, dim3((count + 63) / 64), dim3(64), 0, st, (const StepParams *)e->d_sp, ids, ids32, count_dev, count);
+    if (mode == MODE_STEP) hipLaunchKernelGGL(k_env_post<MODE_STEP>, dim3(grid), dim3(64), e->lds_bytes, st, (const StepParams *)e->d_sp, ids, ids32, count_dev, count);
+    else hipLaunchKernelGGL(k_env_post<MODE_OBS>, dim3(grid), dim3(64), e->lds_bytes, st, (const StepParams *)e->d_sp, ids, ids32, count_dev, count);
     HIPCHK(hipGetLastError());
     return PARC_OK;
 }
@@ -1337,6 +1499,21 @@ extern "C" int parc_env_get_frame_vel_tables(ParcEnv *e, float *root_vel, float 
         if (dof_vel) for (int d = 0; d < e->D; ++d) dof_vel[(size_t)f * e->D + d] = v[8 + d];
     }
     return PARC_OK;
+}
+
+// Diagnostic (-DPARC_STAMPS builds): mean cycles per phase of k_env_post over all envs of the last step.
+extern "C" int parc_env_debug_stamps(ParcEnv *e, double *mean8) {
+#ifdef PARC_STAMPS
+    if (!e || !e->sp.stamp_out) return fail(PARC_ERR_STATE, "no stamp buffer");
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<unsigned> h((size_t)e->N * 8);
+    HIPCHK(hipMemcpy(h.data(), e->sp.stamp_out, h.size() * 4, hipMemcpyDeviceToHost));
+    for (int k = 0; k < 8; ++k) { double a = 0; for (int i = 0; i < e->N; ++i) a += h[(size_t)i * 8 + k]; mean8[k] = a / e->N; }
+    return PARC_OK;
+#else
+    (void)e; (void)mean8;
+    return fail(PARC_ERR_STATE, "library built without PARC_STAMPS");
+#endif
 }
 
 extern "C" int parc_env_profile_step(ParcEnv *e, const float *action_dev, void *stream, int32_t iters, float *avg_ms, float *avg_post_ms) {

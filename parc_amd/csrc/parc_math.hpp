@@ -109,10 +109,24 @@ __device__ __forceinline__ float quat_diff_angle(Q4 q0, Q4 q1) {
 // torch_util.py:470-472
 __device__ __forceinline__ Q4 quat_normalize(Q4 q) { return normalize4(quat_pos(q)); }
 
+// quat_rotate(q, (1,0,0)) and quat_rotate(q, (0,0,1)) with the multiplications by the 0/1 components of v
+// carried out symbolically: x*0 = +-0 and a + (+-0) = a, so every surviving operation is the one the generic
+// formula performs, in the same order — results are identical up to the sign of an exact zero.
+__device__ __forceinline__ V3 quat_rotate_x(Q4 q) { // v = (1,0,0): t = 2(0, qz, -qy)
+    const float ty = 2.f * q.z, tz = 2.f * (-q.y);
+    const float cx = q.y * tz - q.z * ty, cy = -(q.x * tz), cz = q.x * ty;
+    return mk3(1.f + cx, q.w * ty + cy, q.w * tz + cz);
+}
+__device__ __forceinline__ V3 quat_rotate_z(Q4 q) { // v = (0,0,1): t = 2(qy, -qx, 0)
+    const float tx = 2.f * q.y, ty = 2.f * (-q.x);
+    const float cx = -(q.z * ty), cy = q.z * tx, cz = q.x * ty - q.y * tx;
+    return mk3(q.w * tx + cx, q.w * ty + cy, 1.f + cz);
+}
+
 // torch_util.py:393-404: [rot(q,(1,0,0)), rot(q,(0,0,1))]
 __device__ __forceinline__ void quat_to_tan_norm(Q4 q, float *o) {
-    V3 t = quat_rotate(q, mk3(1.f, 0.f, 0.f));
-    V3 n = quat_rotate(q, mk3(0.f, 0.f, 1.f));
+    V3 t = quat_rotate_x(q);
+    V3 n = quat_rotate_z(q);
     o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = n.x; o[4] = n.y; o[5] = n.z;
 }
 
@@ -134,7 +148,7 @@ __device__ __forceinline__ Q4 slerp(Q4 q0, Q4 q1, float t) {
 
 // torch_util.py:502-511
 __device__ __forceinline__ float calc_heading(Q4 q) {
-    V3 d = quat_rotate(q, mk3(1.f, 0.f, 0.f));
+    V3 d = quat_rotate_x(q);
     return atan2f(d.y, d.x);
 }
 

@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libparc_env.so")
+# PARC_ENV_LIB: developer override used to A/B kernel builds; the shipped library is the in-tree one
+LIB_PATH = os.environ.get("PARC_ENV_LIB") or os.path.join(_HERE, "libparc_env.so")
 
 ABI_VERSION = 1
 MAX_BODIES, MAX_DOFS, MAX_TAR_STEPS, MAX_KEY, MAX_FK_PATHS, MAX_FK_DEPTH, MAX_GEOMS = 16, 40, 6, 8, 8, 8, 24
