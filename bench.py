@@ -139,6 +139,14 @@ def main():
     # dominant kernel, measured live with hipEvents on the launch stream
     tot_ms, post_ms = env.profile_step(iters=20, action=actions[0])
     bytes_per = BYTES_DYNAMICS if dynamics_on else BYTES_KINEMATIC
+    # HBM traffic from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs; FETCH_SIZE
+    # doubled per the gfx950 correction).  Only valid for the configuration it was collected on.
+    traffic = None
+    pmc_path = os.path.join(REPO, "profiles", "r01_pmc_hbm_traffic.json")
+    if os.path.exists(pmc_path) and a.envs == 65536 and not dynamics_on:
+        pmc = json.load(open(pmc_path))
+        k = "void k_env_post<0>"
+        traffic = (2.0 * pmc["FETCH_SIZE_KiB_avg_per_dispatch"][k] + pmc["WRITE_SIZE_KiB_avg_per_dispatch"][k]) * 1024.0
     achieved = bytes_per * a.envs / (post_ms * 1e-3) / 1e9
     out = {
         "metric": "env-steps/s", "value": a.envs * world * a.steps / dt, "unit": "env-steps/s", "n_gpus": world,
@@ -148,7 +156,7 @@ def main():
                                + f", {a.envs} envs per GPU, 5 bundled clips on a square blocky grid, reset of finished envs included",
                    "envs_per_gpu": a.envs, "total_envs": a.envs * world, "dynamics": dynamics_on, "parallelism": f"env-shard x{world}"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "kernel": "k_env_post<MODE_STEP>", "kernel_ms": post_ms,
+                     "traffic": traffic, "kernel": "k_env_post<MODE_STEP>", "kernel_ms": post_ms,
                      "algorithmic_bytes_per_env_step": bytes_per},
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

@@ -724,32 +724,58 @@ __global__ __launch_bounds__(1024) void k_done_scatter(const unsigned char *__re
     if (b == (int)gridDim.x - 1 && tid == 0) *reset_count = s_base + total;
 }
 
-// One wave per motion: walk the env-ordered list 64 entries at a time, apply the chain in order.
+// One 256-thread block per motion.  The block sweeps the env-ordered list and compacts (stable, by rank) the
+// FAIL flags of its motion's entries into an LDS bit string; thread 0 then applies the chain in that order:
+// f <- f*(1-w) + (FAIL ? w : 0)  (adding +0.0f leaves f*(1-w) unchanged, so this is the reference's two-branch
+// update, dm_env.py:651-658, bit for bit).
+#define EMA_CAP_BITS 65536
 __global__ __launch_bounds__(256) void k_fail_rate_ema(const int *__restrict__ done_key, const int *__restrict__ reset_count,
                                                        float *fail_rates, int M, float w) {
-    const int lane = threadIdx.x & 63;
-    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (m >= M) return;
+    __shared__ unsigned s_bits[EMA_CAP_BITS / 32];
+    __shared__ int s_wtot[4];
+    __shared__ float s_f;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = blockIdx.x;
     const int k = *reset_count;
-    if (k == 0) return;
+    if (k == 0 || m >= M) return;
     const float keep = (float)(1.0 - (double)w);
-    float f = fail_rates[m];
+    for (int i = tid; i < EMA_CAP_BITS / 32; i += 256) s_bits[i] = 0u;
+    if (tid == 0) s_f = fail_rates[m];
+    __syncthreads();
+    int nmatch = 0;
     bool any = false;
-    for (int base = 0; base < k; base += 64) {
-        const int i = base + lane;
+    for (int tile = 0; tile < k; tile += 256) {
+        const int i = tile + tid;
         const int v = i < k ? done_key[i] : -2;
         const bool match = (v >> 1) == m;
-        unsigned long long mask = __ballot(match);
-        if (!mask) continue;
-        any = true;
-        const unsigned long long failmask = __ballot(match && (v & 1));
-        while (mask) {
-            const int bit = __ffsll((long long)mask) - 1;
-            f = ((failmask >> bit) & 1ull) ? (f * keep + w) : (f * keep);
-            mask &= mask - 1ull;
+        const unsigned long long mask = __ballot(match);
+        if (lane == 0) s_wtot[wv] = __popcll(mask);
+        __syncthreads();
+        int woff = 0, total = 0;
+        for (int q = 0; q < 4; ++q) { const int c = s_wtot[q]; if (q < wv) woff += c; total += c; }
+        if (match && (v & 1)) {
+            const int pos = nmatch + woff + __popcll(mask & ((1ull << lane) - 1ull));
+            atomicOr(&s_bits[pos >> 5], 1u << (pos & 31));
+        }
+        nmatch += total;
+        any = any || total > 0;
+        __syncthreads();
+        const bool last = tile + 256 >= k;
+        if (nmatch + 256 > EMA_CAP_BITS || (last && nmatch > 0)) { // flush: sequential chain over the buffered flags
+            if (tid == 0) {
+                float f = s_f;
+                for (int j = 0; j < nmatch; ++j) {
+                    const float add = ((s_bits[j >> 5] >> (j & 31)) & 1u) ? w : 0.0f;
+                    f = f * keep + add;
+                }
+                s_f = f;
+            }
+            __syncthreads();
+            if (!last) for (int q = tid; q < EMA_CAP_BITS / 32; q += 256) s_bits[q] = 0u;
+            nmatch = 0;
+            __syncthreads();
         }
     }
-    if (lane == 0 && any) fail_rates[m] = f;
+    if (tid == 0 && any) fail_rates[m] = s_f;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1321,7 +1347,7 @@ static int check_ready(ParcEnv *e) {
 static int launch_curriculum(ParcEnv *e, hipStream_t st) {
     hipLaunchKernelGGL(k_done_scatter, dim3(e->nchunks), dim3(1024), 0, st, e->d_ema, e->sp.buf.motion_ids, e->N, e->d_done_list,
                        e->d_done_key, e->d_reset_count);
-    hipLaunchKernelGGL(k_fail_rate_ema, dim3((e->M + 3) / 4), dim3(256), 0, st, e->d_done_key, e->d_reset_count, e->d_fail, e->M,
+    hipLaunchKernelGGL(k_fail_rate_ema, dim3(e->M), dim3(256), 0, st, e->d_done_key, e->d_reset_count, e->d_fail, e->M,
                        e->cfg.fail_rate_ema_weight);
     HIPCHK(hipGetLastError());
     return PARC_OK;
