@@ -26,6 +26,7 @@ sys.path.insert(0, REPO)
 # SURVEY.md §8(d) / BASELINE.md §4: algorithmic HBM bytes per env-step
 BYTES_KINEMATIC = 5772   # read state 276 + contact forces 180 + bookkeeping 24; write obs 5248 + reward/done/terms 44
 BYTES_DYNAMICS = 6340    # + action 112, state write-back 276, contact-force write 180
+BYTES_DYN_KERNEL = 844   # k_dynamics alone: state 276 + action 112 in, state 276 + contact forces 180 out
 HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: 8 TB/s spec
 
 
@@ -38,12 +39,13 @@ def parse():
     ap.add_argument("--config", default=os.path.join(REPO, "data/configs/tracker_config/dm_env_default.yaml"))
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dynamics", type=int, default=-1, help="-1: whatever the build supports; 0/1 force")
+    ap.add_argument("--dynamics", type=int, default=1, help="1: full step (rigid-body dynamics + contact), 0: kinematic step only")
     return ap.parse_args()
 
 
-def cpu_baseline(env, seconds):
-    """Time the CPU oracle (oracle/parc_oracle.c) on the same scene/state, all host cores, bounded sample."""
+def cpu_baseline(env, seconds, dynamics_on, actions):
+    """Time the CPU oracle (oracle/parc_oracle.c [+ the host build of the dynamics core]) on the same scene/state,
+    all host cores, bounded sample."""
     import numpy as np
     sys.path.insert(0, os.path.join(REPO, "tests"))
     from oracle.binding import Oracle
@@ -69,9 +71,25 @@ def cpu_baseline(env, seconds):
     cores = max(1, min(os.cpu_count() or 1, 64))
     bounds = np.linspace(0, n, cores + 1).astype(int)
 
+    dyn = None
+    if dynamics_on:
+        from oracle.binding_dyn import DynOracle
+        dyn = DynOracle(sc.cfg)
+        act = actions[0].cpu().numpy()
+        hf_t, mp_t, dx_t = sc.grid.terrain.hf, sc.grid.terrain.min_point, sc.grid.terrain.dxdy
+        dst = dict(root_pos=st["char_root_pos"], root_rot=st["char_root_rot"], root_vel=st["char_root_vel"],
+                   root_ang_vel=st["char_root_ang_vel"], dof_pos=st["char_dof_pos"], dof_vel=st["char_dof_vel"],
+                   contact_force=st["contact_forces"])
+
+    def work(b0, b1):
+        if dyn is not None:
+            dyn.step(hf_t, mp_t, dx_t, {k: v[b0:b1] for k, v in dst.items()}, act[b0:b1], sc.env_offsets[b0:b1])
+            jr = oracle.dof_to_rot(oc, st["char_dof_pos"][b0:b1])
+            st["char_body_pos"][b0:b1] = oracle.forward_kinematics(oc, st["char_root_pos"][b0:b1], st["char_root_rot"][b0:b1], jr)[0]
+        oracle.env_post_physics_step(oc, lib, ter, ocfg, st, b0, b1)
+
     def run_step():
-        th = [threading.Thread(target=oracle.env_post_physics_step, args=(oc, lib, ter, ocfg, st, int(bounds[i]), int(bounds[i + 1])))
-              for i in range(cores)]
+        th = [threading.Thread(target=work, args=(int(bounds[i]), int(bounds[i + 1]))) for i in range(cores)]
         for t in th: t.start()
         for t in th: t.join()
         oracle.env_update_curriculum(lib, ocfg, st)
@@ -84,7 +102,8 @@ def cpu_baseline(env, seconds):
         run_step(); steps += 1
     dt = time.time() - t0
     return {"value": n * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} kinematic steps x {n} envs, C oracle (scalar, -O2, one thread per core), same scene and state"}
+            "sample": f"{steps} {'full (dynamics + obs/reward/done)' if dynamics_on else 'kinematic'} steps x {n} envs, C/C++ oracle "
+                      "(scalar, -O2, one thread per core), same scene and state"}
 
 
 def main():
@@ -101,7 +120,7 @@ def main():
     from parc_amd.envs.hip_parkour_env import HipParkourEnv
     from parc_amd.util import path_loader
     cfg = path_loader.load_config(a.config)
-    dyn = None if a.dynamics < 0 else bool(a.dynamics)
+    dyn = bool(a.dynamics)
     sys.stdout = sys.stderr if rank == 0 else open(os.devnull, "w")  # the only stdout line is the JSON below
     env = HipParkourEnv(cfg, a.envs, dev, False, env_id_base=rank * a.envs, total_envs=world * a.envs, seed=1234 + rank,
                         mirror_ref_state=False, enable_dynamics=dyn)
@@ -138,16 +157,21 @@ def main():
 
     # dominant kernel, measured live with hipEvents on the launch stream
     tot_ms, post_ms = env.profile_step(iters=20, action=actions[0])
-    bytes_per = BYTES_DYNAMICS if dynamics_on else BYTES_KINEMATIC
-    # HBM traffic from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs; FETCH_SIZE
-    # doubled per the gfx950 correction).  Only valid for the configuration it was collected on.
-    traffic = None
+    dyn_ms = float(env._lib.parc_env_last_dynamics_ms(env._handle))
+    # HBM traffic of k_env_post from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs;
+    # FETCH_SIZE doubled per the gfx950 correction).  Only valid for the configuration it was collected on.
+    post_traffic = None
     pmc_path = os.path.join(REPO, "profiles", "r01_pmc_hbm_traffic.json")
-    if os.path.exists(pmc_path) and a.envs == 65536 and not dynamics_on:
+    if os.path.exists(pmc_path) and a.envs == 65536:
         pmc = json.load(open(pmc_path))
         k = "void k_env_post<0>"
-        traffic = (2.0 * pmc["FETCH_SIZE_KiB_avg_per_dispatch"][k] + pmc["WRITE_SIZE_KiB_avg_per_dispatch"][k]) * 1024.0
-    achieved = bytes_per * a.envs / (post_ms * 1e-3) / 1e9
+        post_traffic = (2.0 * pmc["FETCH_SIZE_KiB_avg_per_dispatch"][k] + pmc["WRITE_SIZE_KiB_avg_per_dispatch"][k]) * 1024.0
+    post_gbs = BYTES_KINEMATIC * a.envs / (post_ms * 1e-3) / 1e9
+    if dynamics_on:   # dominant kernel = k_dynamics: state 276 + action 112 in, state 276 + contact forces 180 out
+        kname, kms, bytes_per, traffic = "k_dynamics", dyn_ms, BYTES_DYN_KERNEL, None
+    else:
+        kname, kms, bytes_per, traffic = "k_env_prep + k_env_post<MODE_STEP>", post_ms, BYTES_KINEMATIC, post_traffic
+    achieved = bytes_per * a.envs / (kms * 1e-3) / 1e9
     out = {
         "metric": "env-steps/s", "value": a.envs * world * a.steps / dt, "unit": "env-steps/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
@@ -156,11 +180,15 @@ def main():
                                + f", {a.envs} envs per GPU, 5 bundled clips on a square blocky grid, reset of finished envs included",
                    "envs_per_gpu": a.envs, "total_envs": a.envs * world, "dynamics": dynamics_on, "parallelism": f"env-shard x{world}"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "kernel": "k_env_post<MODE_STEP>", "kernel_ms": post_ms,
-                     "algorithmic_bytes_per_env_step": bytes_per},
+                     "traffic": traffic, "kernel": kname, "kernel_ms": kms, "algorithmic_bytes_per_env_step": bytes_per,
+                     "note": "k_dynamics is latency/scratch bound by construction (SURVEY 8d), far below the HBM ceiling",
+                     "obs_kernel": {"kernel": "k_env_prep + k_env_post<MODE_STEP>", "kernel_ms": post_ms, "achieved": post_gbs,
+                                    "frac": post_gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_env_step": BYTES_KINEMATIC,
+                                    "traffic": post_traffic},
+                     "whole_step_algorithmic_bytes": BYTES_DYNAMICS if dynamics_on else BYTES_KINEMATIC},
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(env, a.cpu_seconds)
+        out["cpu_baseline"] = cpu_baseline(env, a.cpu_seconds, dynamics_on, actions)
     if rank == 0:
         sys.stdout = sys.__stdout__
         print(json.dumps(out))

@@ -225,6 +225,9 @@ int parc_env_get_frame_vel_tables(ParcEnv *env, float *root_vel_host, float *roo
 int parc_env_profile_step(ParcEnv *env, const float *action_dev, void *stream, int32_t iters, float *avg_ms_out,
                           float *avg_post_kernel_ms_out);
 
+/* average duration of k_dynamics in the last parc_env_profile_step call (0 when dynamics is off) */
+float parc_env_last_dynamics_ms(ParcEnv *env);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,59 @@
+"""ctypes binding of the CPU build of the dynamics core (oracle/dyn_oracle.cpp).  TEST INFRASTRUCTURE ONLY."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libdyn_oracle.so")
+f32p = C.POINTER(C.c_float)
+
+
+def build(force=False):
+    deps = [os.path.join(_HERE, "dyn_oracle.cpp"), os.path.join(_HERE, "..", "parc_amd", "csrc", "parc_dynamics.hpp"),
+            os.path.join(_HERE, "..", "include", "parc_env.h")]
+    if force or not os.path.exists(_LIB) or any(os.path.getmtime(d) > os.path.getmtime(_LIB) for d in deps):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "libdyn_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB
+
+
+def _p(a):
+    assert a.dtype == np.float32 and a.flags.c_contiguous
+    return a.ctypes.data_as(f32p)
+
+
+class DynOracle:
+    def __init__(self, cfg_struct):
+        """cfg_struct: parc_amd.lib.ParcEnvConfig (model + dynamics + action bounds)."""
+        self.lib = C.CDLL(build())
+        self.lib.orc_dyn_create.restype = C.c_void_p
+        self.B = cfg_struct.model.num_bodies
+        self.D = cfg_struct.model.dof_size
+        lo = np.array(list(cfg_struct.action_low)[: self.D], np.float32)
+        hi = np.array(list(cfg_struct.action_high)[: self.D], np.float32)
+        self.h = C.c_void_p(self.lib.orc_dyn_create(C.byref(cfg_struct.model), C.byref(cfg_struct.dynamics), _p(lo), _p(hi)))
+
+    def mass_properties(self):
+        mass = np.zeros(self.B, np.float32); com = np.zeros((self.B, 3), np.float32); inertia = np.zeros((self.B, 6), np.float32)
+        total = C.c_float(); ncol = C.c_int()
+        self.lib.orc_dyn_get_mass(self.h, _p(mass), _p(com), _p(inertia), C.byref(total), C.byref(ncol))
+        return mass, com, inertia, total.value, ncol.value
+
+    def set_gravity(self, g):
+        self.lib.orc_dyn_set_gravity(self.h, C.c_float(g))
+
+    def set_contact(self, kn, dn, dtang, mu):
+        self.lib.orc_dyn_set_contact(self.h, C.c_float(kn), C.c_float(dn), C.c_float(dtang), C.c_float(mu))
+
+    def scale_gains(self, s):
+        self.lib.orc_dyn_set_gains_scale(self.h, C.c_float(s))
+
+    def step(self, hf, min_point, dxdy, st, action, env_off):
+        """st: dict of float32 arrays root_pos[n,3], root_rot[n,4], root_vel, root_ang_vel, dof_pos[n,D], dof_vel, contact_force[n,B,3]."""
+        hf = np.ascontiguousarray(hf, np.float32)
+        n = st["root_pos"].shape[0]
+        self.lib.orc_dyn_step(self.h, _p(hf), C.c_int(hf.shape[0]), C.c_int(hf.shape[1]), C.c_float(min_point[0]), C.c_float(min_point[1]),
+                              C.c_float(dxdy[0]), C.c_float(dxdy[1]), C.c_int(n), _p(st["root_pos"]), _p(st["root_rot"]), _p(st["root_vel"]),
+                              _p(st["root_ang_vel"]), _p(st["dof_pos"]), _p(st["dof_vel"]), _p(st["contact_force"]),
+                              _p(np.ascontiguousarray(action, np.float32)), _p(np.ascontiguousarray(env_off, np.float32)))

@@ -1,0 +1,55 @@
+// dyn_oracle.cpp — CPU build (g++) of the re-authored dynamics core, for tests only.
+// TEST INFRASTRUCTURE: compiled from the product's own portable header parc_amd/csrc/parc_dynamics.hpp so that
+// (a) the invariants tests (momentum, energy, resting contact, PD response) run without a GPU and
+// (b) the HIP kernel can be checked against the identical arithmetic on the host.  PhysX parity is unpinned.
+#include <cstring>
+#include <vector>
+
+#include "../parc_amd/csrc/parc_dynamics.hpp"
+
+using namespace parcdyn;
+
+extern "C" {
+
+void *orc_dyn_create(const ParcCharModel *cm, const ParcDynamicsParams *dp, const float *act_lo, const float *act_hi) {
+    DynModel *M = new DynModel();
+    memset(M, 0, sizeof(DynModel));
+    fill_dyn_model(*M, *cm, *dp, act_lo, act_hi);
+    return M;
+}
+void orc_dyn_destroy(void *m) { delete (DynModel *)m; }
+
+void orc_dyn_set_contact(void *m, float kn, float dn, float dtang, float mu) {
+    DynModel *M = (DynModel *)m;
+    M->kn = kn; M->dn = dn; M->dtang = dtang; M->mu = mu;
+}
+void orc_dyn_set_gravity(void *m, float g) { ((DynModel *)m)->gravity_z = g; }
+void orc_dyn_set_gains_scale(void *m, float s) {
+    DynModel *M = (DynModel *)m;
+    for (int d = 0; d < M->D; ++d) { M->kp[d] *= s; M->kd[d] *= s; }
+}
+void orc_dyn_get_mass(void *m, float *mass, float *com, float *inertia, float *total, int *ncol) {
+    DynModel *M = (DynModel *)m;
+    for (int b = 0; b < M->B; ++b) {
+        mass[b] = M->mass[b];
+        for (int k = 0; k < 3; ++k) com[3 * b + k] = M->com[b][k];
+        for (int k = 0; k < 6; ++k) inertia[6 * b + k] = M->inertia[b][k];
+    }
+    *total = M->total_mass; *ncol = M->ncol;
+}
+
+// state arrays are [n][...] row-major like the env tensors
+void orc_dyn_step(void *m, const float *hf, int X, int Y, float min_x, float min_y, float dx, float dy, int n, float *root_pos,
+                  float *root_rot, float *root_vel, float *root_ang_vel, float *dof_pos, float *dof_vel, float *contact_force,
+                  const float *action, const float *env_off) {
+    const DynModel &M = *(DynModel *)m;
+    DynTerrain T; T.hf = hf; T.X = X; T.Y = Y; T.min_x = min_x; T.min_y = min_y; T.dx = dx; T.dy = dy;
+    for (int e = 0; e < n; ++e) {
+        DynState S;
+        S.root_pos = root_pos + 3 * (size_t)e; S.root_rot = root_rot + 4 * (size_t)e; S.root_vel = root_vel + 3 * (size_t)e;
+        S.root_ang_vel = root_ang_vel + 3 * (size_t)e; S.dof_pos = dof_pos + (size_t)M.D * e; S.dof_vel = dof_vel + (size_t)M.D * e;
+        S.contact_force = contact_force + (size_t)3 * M.B * e; S.body_pos = nullptr;
+        dyn_control_step(M, T, S, action + (size_t)M.D * e, env_off + 3 * (size_t)e);
+    }
+}
+}

@@ -24,6 +24,7 @@
 
 #include "../../include/parc_env.h"
 #include "parc_math.hpp"
+#include "parc_dynamics.hpp"
 
 using namespace parc;
 
@@ -131,6 +132,24 @@ __device__ __forceinline__ int cell_index(float p, float mn, float d) {
     float f = rintf((p - mn) / d);
     f = fminf(fmaxf(f, -1.0e9f), 1.0e9f);
     return (int)f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_dynamics: one THREAD per env advances the articulated character by one control step (nsub solver
+// substeps) — clip action -> PD targets -> ABA with implicit drives and implicit cell-column contact
+// (parc_dynamics.hpp).  Replaces gym.set_dof_position_target_tensor + gym.simulate x sim_steps + refresh_*
+// (ig_char_env.py:488-497, ig_env.py:359-389).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_dynamics(const parcdyn::DynModel *__restrict__ M, parcdyn::DynTerrain T, ParcEnvBuffers buf,
+                                                 const float *__restrict__ action, const float *__restrict__ env_off, int N) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N) return;
+    parcdyn::DynState S;
+    S.root_pos = buf.char_root_pos + 3 * (size_t)e; S.root_rot = buf.char_root_rot + 4 * (size_t)e;
+    S.root_vel = buf.char_root_vel + 3 * (size_t)e; S.root_ang_vel = buf.char_root_ang_vel + 3 * (size_t)e;
+    S.dof_pos = buf.char_dof_pos + (size_t)M->D * e; S.dof_vel = buf.char_dof_vel + (size_t)M->D * e;
+    S.contact_force = buf.contact_forces + (size_t)3 * M->B * e; S.body_pos = nullptr;
+    parcdyn::dyn_control_step(*M, T, S, action + (size_t)M->D * e, env_off + 3 * (size_t)e);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1057,6 +1076,8 @@ struct ParcEnv {
     StepParams sp;
     StepParams *d_sp = nullptr;
     float4 *d_prep = nullptr;
+    parcdyn::DynModel h_dyn;
+    parcdyn::DynModel *d_dyn = nullptr;
     DevTables h_tab;
     DevTables *d_tab = nullptr;
     float *d_ray = nullptr, *d_env_off = nullptr, *d_hf = nullptr, *d_motion_off = nullptr;
@@ -1073,6 +1094,7 @@ struct ParcEnv {
     unsigned long long reset_calls = 0;
     int grid_waves = 0;
     size_t lds_bytes = 0;
+    float last_dyn_ms = 0.f;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
@@ -1080,7 +1102,7 @@ extern "C" const char *parc_last_error(void) { return g_err.c_str(); }
 extern "C" int parc_abi_version(void) { return PARC_ABI_VERSION; }
 
 static void free_dev(ParcEnv *e) {
-    void *ptrs[] = {e->d_sp, e->d_prep, e->d_tab, e->d_ray, e->d_env_off, e->d_hf, e->d_motion_off, e->d_records, e->d_meta, e->d_weights, e->d_fail,
+    void *ptrs[] = {e->d_sp, e->d_prep, e->d_dyn, e->d_tab, e->d_ray, e->d_env_off, e->d_hf, e->d_motion_off, e->d_records, e->d_meta, e->d_weights, e->d_fail,
                     e->d_cdf, e->d_ema, e->d_done_list, e->d_done_key, e->d_chunk_count, e->d_motion_done, e->d_reset_count, e->d_tmp_mid, e->d_tmp_tid, e->d_tmp_t0, e->d_tmp_noise,
                     e->d_scratch_jr};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -1106,7 +1128,10 @@ extern "C" int parc_env_create(const ParcEnvConfig *cfg, ParcEnv **out) {
     if (!cfg->env_offsets_host) return fail(PARC_ERR_INVALID, "env_offsets_host is required");
     for (int b = 1; b < m.num_bodies; ++b)
         if (m.parent[b] < 0 || m.parent[b] >= b) return fail(PARC_ERR_INVALID, "bodies must be in DFS order (parent < child)");
-    if (cfg->enable_dynamics) return fail(PARC_ERR_INVALID, "enable_dynamics: this build ships the kinematic step only");
+    if (cfg->enable_dynamics && !cfg->body_pos_from_fk)
+        return fail(PARC_ERR_INVALID, "enable_dynamics needs body_pos_from_fk = 1 (the simulator is reduced-coordinate)");
+    if (cfg->enable_dynamics && (cfg->dynamics.num_geoms < 1 || cfg->dynamics.num_geoms > PARC_MAX_GEOMS || !(cfg->dynamics.sim_dt > 0.f)))
+        return fail(PARC_ERR_INVALID, "enable_dynamics: bad ParcDynamicsParams");
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(PARC_ERR_NO_DEVICE, "no HIP device visible");
@@ -1191,6 +1216,14 @@ extern "C" int parc_env_create(const ParcEnvConfig *cfg, ParcEnv **out) {
         (r = up((void **)&e->d_scratch_jr, nullptr, sizeof(float) * 4 * J * N)) != hipSuccess) {
         free_dev(e); delete e;
         return fail(PARC_ERR_HIP, std::string("device allocation failed: ") + hipGetErrorString(r));
+    }
+    if (cfg->enable_dynamics) {
+        memset(&e->h_dyn, 0, sizeof(e->h_dyn));
+        parcdyn::fill_dyn_model(e->h_dyn, cfg->model, cfg->dynamics, cfg->action_low, cfg->action_high);
+        if ((r = up((void **)&e->d_dyn, &e->h_dyn, sizeof(e->h_dyn))) != hipSuccess) {
+            free_dev(e); delete e;
+            return fail(PARC_ERR_HIP, std::string("device allocation failed: ") + hipGetErrorString(r));
+        }
     }
     for (auto &ev : e->ev) (void)hipEventCreate(&ev);
     sp.tables = e->d_tab; sp.ray_points = e->d_ray; sp.env_offsets = e->d_env_off;
@@ -1344,6 +1377,17 @@ static int check_ready(ParcEnv *e) {
     return PARC_OK;
 }
 
+static int launch_dynamics(ParcEnv *e, const float *action_dev, hipStream_t st) {
+    if (!e->cfg.enable_dynamics) return PARC_OK;
+    if (!action_dev) return fail(PARC_ERR_INVALID, "action is required when enable_dynamics is set");
+    parcdyn::DynTerrain T;
+    T.hf = e->d_hf; T.X = e->sp.X; T.Y = e->sp.Y; T.min_x = e->sp.min_x; T.min_y = e->sp.min_y; T.dx = e->sp.dx; T.dy = e->sp.dy;
+    hipLaunchKernelGGL(k_dynamics, dim3((e->N + 63) / 64), dim3(64), 0, st, (const parcdyn::DynModel *)e->d_dyn, T, e->sp.buf, action_dev,
+                       (const float *)e->d_env_off, e->N);
+    HIPCHK(hipGetLastError());
+    return PARC_OK;
+}
+
 static int launch_curriculum(ParcEnv *e, hipStream_t st) {
     hipLaunchKernelGGL(k_done_scatter, dim3(e->nchunks), dim3(1024), 0, st, e->d_ema, e->sp.buf.motion_ids, e->N, e->d_done_list,
                        e->d_done_key, e->d_reset_count);
@@ -1367,8 +1411,9 @@ static int launch_post(ParcEnv *e, int mode, const int64_t *ids, int count, hipS
 extern "C" int parc_env_step(ParcEnv *e, const float *action_dev, void *stream) {
     int rc = check_ready(e);
     if (rc) return rc;
-    (void)action_dev;
     hipStream_t st = (hipStream_t)stream;
+    rc = launch_dynamics(e, action_dev, st);
+    if (rc) return rc;
     rc = launch_post(e, MODE_STEP, nullptr, e->N, st);
     if (rc) return rc;
     return launch_curriculum(e, st);
@@ -1527,6 +1572,8 @@ extern "C" int parc_env_get_frame_vel_tables(ParcEnv *e, float *root_vel, float 
     return PARC_OK;
 }
 
+extern "C" float parc_env_last_dynamics_ms(ParcEnv *e) { return e ? e->last_dyn_ms : 0.f; }
+
 // Diagnostic (-DPARC_STAMPS builds): mean cycles per phase of k_env_post over all envs of the last step.
 extern "C" int parc_env_debug_stamps(ParcEnv *e, double *mean8) {
 #ifdef PARC_STAMPS
@@ -1546,10 +1593,12 @@ extern "C" int parc_env_profile_step(ParcEnv *e, const float *action_dev, void *
     int rc = check_ready(e);
     if (rc) return rc;
     if (iters < 1) return fail(PARC_ERR_INVALID, "iters must be >= 1");
-    (void)action_dev;
     hipStream_t st = (hipStream_t)stream;
-    double tot = 0.0, post = 0.0;
+    double tot = 0.0, post = 0.0, dyn = 0.0;
     for (int i = 0; i < iters; ++i) {
+        HIPCHK(hipEventRecord(e->ev[3], st));
+        rc = launch_dynamics(e, action_dev, st);
+        if (rc) return rc;
         HIPCHK(hipEventRecord(e->ev[0], st));
         rc = launch_post(e, MODE_STEP, nullptr, e->N, st);
         if (rc) return rc;
@@ -1558,12 +1607,14 @@ extern "C" int parc_env_profile_step(ParcEnv *e, const float *action_dev, void *
         if (rc) return rc;
         HIPCHK(hipEventRecord(e->ev[2], st));
         HIPCHK(hipEventSynchronize(e->ev[2]));
-        float a = 0.f, b = 0.f;
-        HIPCHK(hipEventElapsedTime(&a, e->ev[0], e->ev[2]));
+        float a = 0.f, b = 0.f, c = 0.f;
+        HIPCHK(hipEventElapsedTime(&a, e->ev[3], e->ev[2]));
         HIPCHK(hipEventElapsedTime(&b, e->ev[0], e->ev[1]));
-        tot += a; post += b;
+        HIPCHK(hipEventElapsedTime(&c, e->ev[3], e->ev[0]));
+        tot += a; post += b; dyn += c;
     }
     if (avg_ms) *avg_ms = (float)(tot / iters);
     if (avg_post_ms) *avg_post_ms = (float)(post / iters);
+    e->last_dyn_ms = (float)(dyn / iters);
     return PARC_OK;
 }
