@@ -374,3 +374,34 @@ def test_dynamics_rollout_sanity(tmp_path):
     assert np.abs(f).max() < 2e4
     # a character that merely replays the clip's joint angles still stays up for a while: mean reward well above a fallen one
     assert to_np(env._reward_buf).mean() > 0.1
+
+
+def test_ppo_training_iterations_on_hip_env(tmp_path):
+    """End to end on the GPU: the PPO learner drives HipParkourEnv (full dynamics) for a few iterations through the
+    reference's call sequence (reset -> [decide, step, reset done] x steps -> TD(lambda) -> minibatch updates)."""
+    import torch
+    from gpu_helpers import default_config, write_motion_yaml
+    from helpers import CLIPS4
+    from parc_amd.envs.hip_parkour_env import HipParkourEnv
+    from parc_amd.learning.dm_ppo_agent import DMPPOAgent
+    from parc_amd.util import path_loader
+    from conftest import DATA
+    import os
+    cfg = default_config()
+    cfg["env"]["dm"]["motion_file"] = write_motion_yaml(tmp_path, CLIPS4, [1, 1, 1, 1])
+    env = HipParkourEnv(cfg, 512, "cuda:0", False, seed=2, enable_dynamics=True, mirror_ref_state=False)
+    acfg = path_loader.load_config(os.path.join(DATA, "configs/tracker_config/dm_agent_default.yaml"))
+    acfg["steps_per_iter"] = 8
+    agent = DMPPOAgent(acfg, env, "cuda:0")
+    assert agent.calc_num_params() == 10638877
+    agent._curr_obs, agent._curr_info = env.reset()
+    agent._init_train()
+    for it in range(2):
+        info = agent._train_iter()
+        agent._sample_count = agent._exp_buffer.get_total_samples()
+        assert np.isfinite(info["loss"].item()) and np.isfinite(info["critic_loss"].item())
+    assert agent._obs_norm.get_count().item() == 2 * 8 * 512
+    assert torch.isfinite(agent._exp_buffer.get_data("obs")).all()
+    agent.save(str(tmp_path / "model.pt"))
+    sd = torch.load(str(tmp_path / "model.pt"), weights_only=True)
+    assert "_model._actor_layers.0.weight" in sd and "_obs_norm._mean" in sd

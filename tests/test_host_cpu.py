@@ -1,0 +1,140 @@
+"""CPU tests of the host side: C-ABI export / struct layout, data-only .pkl reader, MJCF parser, scene assembly,
+terrain builder, config handling.  No compute call needs a GPU."""
+import ctypes as C
+import os
+import pickle
+import re
+
+import numpy as np
+import pytest
+
+from conftest import DATA, REPO, golden
+from parc_amd import lib as L
+from parc_amd import ms_file, terrain
+from parc_amd.char_model import CharModel, JointType
+from parc_amd.envs import scene
+from parc_amd.util import path_loader
+
+
+def default_config():
+    return path_loader.load_config(os.path.join(DATA, "configs/tracker_config/dm_env_default.yaml"))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(REPO, "include", "parc_env.h")).read()
+    declared = set(re.findall(r"\b(parc_[a-z_0-9]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    so = C.CDLL(L.LIB_PATH)
+    for sym in sorted(declared):
+        assert hasattr(so, sym), f"{sym} declared in include/parc_env.h but not exported"
+    assert declared == set(L.EXPORTED_SYMBOLS)
+    assert so.parc_abi_version() == L.ABI_VERSION
+
+
+def test_struct_layout_matches_c_and_create_fails_loudly_without_gpu():
+    """parc_env_create validates abi_version/struct_size before touching the device: the ctypes mirror must have the
+    C layout.  Without a GPU the call must fail (no silent CPU path)."""
+    lib = L.load()
+    sc = scene.build_scene(default_config(), 8, verbose=False)
+    h = C.c_void_p()
+    bad = L.ParcEnvConfig.from_buffer_copy(sc.cfg)
+    bad.struct_size = C.sizeof(L.ParcEnvConfig) - 4
+    assert lib.parc_env_create(C.byref(bad), C.byref(h)) == -1
+    assert b"ABI mismatch" in lib.parc_last_error()
+    rc = lib.parc_env_create(C.byref(sc.cfg), C.byref(h))
+    import torch
+    if not torch.cuda.is_available():
+        assert rc == -4 and b"HIP device" in lib.parc_last_error()   # PARC_ERR_NO_DEVICE, not a fallback
+        from parc_amd.envs.hip_parkour_env import HipParkourEnv
+        with pytest.raises(RuntimeError):
+            HipParkourEnv(default_config(), 8, "cuda:0", False)
+    else:
+        assert rc == 0
+        lib.parc_env_destroy(h)
+
+
+def test_ms_file_reader_is_data_only(tmp_path):
+    d = ms_file.load_ms_file(os.path.join(DATA, "motion_terrains", "sfu.pkl"))
+    assert d.motion_data.root_pos.shape == (15, 3) and d.motion_data.fps == 30 and d.motion_data.loop_mode == "CLAMP"
+    assert d.terrain_data.hf.shape == (32, 32) and abs(d.terrain_data.dx - 0.4) < 1e-6
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("echo pwned > /tmp/parc_pwned",))
+    for payload in (pickle.dumps(Evil()), pickle.dumps({"a": Evil()}), pickle.dumps(np.array([Evil()], dtype=object))):
+        with pytest.raises(ms_file.UnsafePickleError):
+            ms_file.loads_data_only(payload)
+    assert not os.path.exists("/tmp/parc_pwned")
+    # round trip through the reference-compatible writer
+    out = tmp_path / "x.pkl"
+    ms_file.save_ms_file(d, str(out))
+    d2 = ms_file.load_ms_file(str(out))
+    assert np.array_equal(d2.motion_data.joint_rot, d.motion_data.joint_rot) and np.array_equal(d2.terrain_data.hf, d.terrain_data.hf)
+    # container layout of the reference (file_io.py:87-103): outer dict of three independently pickled payloads
+    outer = pickle.load(open(out, "rb"))
+    assert set(outer.keys()) == {"motion_data", "terrain_data", "misc_data"} and isinstance(outer["motion_data"], bytes)
+
+
+def test_char_model_matches_reference_tables():
+    g = golden("char_model")
+    cm = CharModel(os.path.join(DATA, "assets", "humanoid.xml"))
+    assert cm.get_body_names() == [str(n) for n in g["body_names"]]
+    assert np.array_equal(cm._parent_indices, g["parent"])
+    assert np.array_equal(cm._local_translation, g["local_translation"]) and np.array_equal(cm._local_rotation, g["local_rotation"])
+    assert np.array_equal(cm.joint_type_array(), g["joint_type"]) and np.array_equal(cm.dof_idx_array(), g["dof_idx"])
+    assert np.array_equal(cm.joint_axis_array(), g["joint_axis"]) and cm.get_dof_size() == int(g["dof_size"])
+    lo, hi = cm.dof_limits()
+    assert np.allclose(lo, g["lower"], atol=1e-7) and np.allclose(hi, g["upper"], atol=1e-7)
+    paths = cm.fk_paths()
+    assert [list(p[p >= 0]) for p in paths[:5]] == [[1, 2], [1, 3, 4, 5], [1, 6, 7, 8], [9, 10, 11], [12, 13, 14]]
+    kp, kd, arm, eff = cm.dof_pd_params()
+    assert kp[0] == 1000 and kd[0] == 100 and abs(arm[0] - 0.02) < 1e-7 and eff[0] == 200 and eff[9] == 70
+
+
+def test_scene_assembly_and_action_bounds():
+    sc = scene.build_scene(default_config(), 16, verbose=False)
+    assert sc.cfg.num_rays == 441 and sc.cfg.num_tar_obs_steps == 6 and sc.key_body_ids == [5, 8, 11, 14]
+    assert sum(int(np.prod(v["shape"])) for v in sc.obs_shapes.values()) == 1312
+    # spherical: +-1.2 max|limit|; hinge: mid +- 0.7 range (ig_char_env.py:307-347)
+    assert np.isclose(sc.action_high[0], 1.2 * np.deg2rad(90)) and np.isclose(sc.action_low[0], -1.2 * np.deg2rad(90))
+    assert np.isclose(sc.action_low[9], np.deg2rad(80) - 0.7 * np.deg2rad(160)) and np.isclose(sc.action_high[9], np.deg2rad(80) + 0.7 * np.deg2rad(160))
+    # env origins: ig_parkour_env.py:389-398; a shard uses its global env indices
+    off = scene.env_offsets_square(16, 2.0)
+    assert np.array_equal(off[5], [4.0, 4.0, 0.0])
+    sh = scene.env_offsets_square(8, 2.0, env_id_base=8, total_envs=16)
+    assert np.array_equal(sh, off[8:16])
+    cfg = default_config(); cfg["env"]["global_obs"] = True
+    with pytest.raises(ValueError):
+        scene.build_scene(cfg, 4, verbose=False)
+    cfg = default_config(); del cfg["env"]["pose_w"]
+    with pytest.raises(KeyError):   # required key, like the reference
+        scene.build_scene(cfg, 4, verbose=False)
+
+
+def test_terrain_square_matches_reference_and_cache_roundtrip(tmp_path):
+    from helpers import load_clips
+    g = golden("env_step")
+    clips = load_clips([str(c) for c in g["clips"]])
+    subs = []
+    for c in clips:
+        t = terrain.SubTerrain(c["hf"].shape[0], c["hf"].shape[1], c["dx"], c["dx"], c["min_point"][0], c["min_point"][1])
+        t.hf = c["hf"].copy(); subs.append(t)
+    grid = terrain.build_terrain_square(subs, 0.4, 0.4)
+    assert np.array_equal(grid.terrain.hf, g["hf"]) and np.array_equal(grid.terrain.min_point, g["hf_min_point"])
+    assert np.array_equal(grid.motion_offsets, g["motion_offsets"])
+    p = str(tmp_path / "terrain.pkl")
+    terrain.save_terrain(grid, p)
+    back = terrain.load_terrain(p)
+    assert np.array_equal(back.terrain.hf, grid.terrain.hf) and np.array_equal(back.motion_offsets, grid.motion_offsets)
+    ray = terrain.get_xy_points_cone(0.05, 2, 60, 3, 3, 0.26179938779)
+    assert np.abs(ray - g["ray_points"]).max() < 5e-7
+    tl = golden("terrain_lookup")
+    t = terrain.SubTerrain(102, 102, 0.4, 0.4, tl["min_point"][0], tl["min_point"][1]); t.hf = tl["hf"]
+    assert np.array_equal(t.get_grid_index(tl["points"]), tl["grid_index"])
+
+
+def test_path_loader_data_dir(monkeypatch, tmp_path):
+    monkeypatch.setenv("PARC_DATA_DIR", str(tmp_path))
+    assert str(path_loader.resolve_path("$DATA_DIR/a/b.yaml")) == str(tmp_path / "a" / "b.yaml")
+    monkeypatch.delenv("PARC_DATA_DIR")
+    assert str(path_loader.resolve_path("$DATA_DIR/assets/humanoid.xml")).endswith("data/assets/humanoid.xml")
