@@ -27,8 +27,16 @@
 
 #if defined(__HIPCC__)
 #define PARC_HD __host__ __device__ __forceinline__
+#define PARC_UNROLL _Pragma("unroll")
 #else
 #define PARC_HD inline
+#define PARC_UNROLL
+#endif
+
+// The dynamics has no bit-exact reference (parity with PhysX is unpinned, the CPU build is compared by tolerance), so the
+// device build may fuse multiply-adds here even though the rest of the library is built with -ffp-contract=off.
+#if defined(__HIPCC__)
+#pragma clang fp contract(fast)
 #endif
 
 namespace parcdyn {
@@ -153,12 +161,22 @@ PARC_HD int sidx(int i, int j) { if (i > j) { int t = i; i = j; j = t; } return 
 PARC_HD float sget(const sym6 &A, int i, int j) { return A.s[sidx(i, j)]; }
 PARC_HD s6 symmul(const sym6 &A, const s6 &x) {
     s6 r;
-    for (int i = 0; i < 6; ++i) { float acc = 0.f; for (int j = 0; j < 6; ++j) acc += sget(A, i, j) * x.a[j]; r.a[i] = acc; }
+    PARC_UNROLL
+    for (int i = 0; i < 6; ++i) {
+        float acc = 0.f;
+        PARC_UNROLL
+        for (int j = 0; j < 6; ++j) acc += sget(A, i, j) * x.a[j];
+        r.a[i] = acc;
+    }
     return r;
 }
 // A += k * w w^T
 PARC_HD void symrank1(sym6 &A, float k, const s6 &w) {
-    for (int i = 0; i < 6; ++i) for (int j = i; j < 6; ++j) A.s[sidx(i, j)] += k * w.a[i] * w.a[j];
+    PARC_UNROLL
+    for (int i = 0; i < 6; ++i) {
+        PARC_UNROLL
+        for (int j = i; j < 6; ++j) A.s[sidx(i, j)] += k * w.a[i] * w.a[j];
+    }
 }
 // spatial inertia about O of a point-like mass m at c plus rotational inertia Ic (world axes): adds into A
 PARC_HD void add_inertia(sym6 &A, float m, v3 c, const float Ic[6] /* xx yy zz xy xz yz or null */) {
@@ -628,3 +646,7 @@ inline void fill_dyn_model(DynModel &M, const ParcCharModel &cm, const ParcDynam
 }
 
 } // namespace parcdyn
+
+#if defined(__HIPCC__)
+#pragma clang fp contract(off)
+#endif

@@ -25,6 +25,7 @@
 #include "../../include/parc_env.h"
 #include "parc_math.hpp"
 #include "parc_dynamics.hpp"
+#include "parc_dynamics_coop.hpp"
 
 using namespace parc;
 
@@ -1078,6 +1079,9 @@ struct ParcEnv {
     float4 *d_prep = nullptr;
     parcdyn::DynModel h_dyn;
     parcdyn::DynModel *d_dyn = nullptr;
+    parcdyn::CoopTables h_coop;
+    parcdyn::CoopTables *d_coop = nullptr;
+    bool use_coop = false;
     DevTables h_tab;
     DevTables *d_tab = nullptr;
     float *d_ray = nullptr, *d_env_off = nullptr, *d_hf = nullptr, *d_motion_off = nullptr;
@@ -1102,7 +1106,7 @@ extern "C" const char *parc_last_error(void) { return g_err.c_str(); }
 extern "C" int parc_abi_version(void) { return PARC_ABI_VERSION; }
 
 static void free_dev(ParcEnv *e) {
-    void *ptrs[] = {e->d_sp, e->d_prep, e->d_dyn, e->d_tab, e->d_ray, e->d_env_off, e->d_hf, e->d_motion_off, e->d_records, e->d_meta, e->d_weights, e->d_fail,
+    void *ptrs[] = {e->d_sp, e->d_prep, e->d_dyn, e->d_coop, e->d_tab, e->d_ray, e->d_env_off, e->d_hf, e->d_motion_off, e->d_records, e->d_meta, e->d_weights, e->d_fail,
                     e->d_cdf, e->d_ema, e->d_done_list, e->d_done_key, e->d_chunk_count, e->d_motion_done, e->d_reset_count, e->d_tmp_mid, e->d_tmp_tid, e->d_tmp_t0, e->d_tmp_noise,
                     e->d_scratch_jr};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -1221,6 +1225,14 @@ extern "C" int parc_env_create(const ParcEnvConfig *cfg, ParcEnv **out) {
         memset(&e->h_dyn, 0, sizeof(e->h_dyn));
         parcdyn::fill_dyn_model(e->h_dyn, cfg->model, cfg->dynamics, cfg->action_low, cfg->action_high);
         if ((r = up((void **)&e->d_dyn, &e->h_dyn, sizeof(e->h_dyn))) != hipSuccess) {
+            free_dev(e); delete e;
+            return fail(PARC_ERR_HIP, std::string("device allocation failed: ") + hipGetErrorString(r));
+        }
+        // chain-parallel kernel when the tree splits into <= 8 chains of <= 4 bodies; PARC_DYN_KERNEL=thread forces
+        // the thread-per-env kernel (kept as the fallback for other trees and as a cross-check)
+        const char *kk = getenv("PARC_DYN_KERNEL");
+        e->use_coop = parcdyn::build_coop_tables(e->h_dyn, e->h_coop) && !(kk && std::string(kk) == "thread");
+        if (e->use_coop && (r = up((void **)&e->d_coop, &e->h_coop, sizeof(e->h_coop))) != hipSuccess) {
             free_dev(e); delete e;
             return fail(PARC_ERR_HIP, std::string("device allocation failed: ") + hipGetErrorString(r));
         }
@@ -1382,8 +1394,12 @@ static int launch_dynamics(ParcEnv *e, const float *action_dev, hipStream_t st) 
     if (!action_dev) return fail(PARC_ERR_INVALID, "action is required when enable_dynamics is set");
     parcdyn::DynTerrain T;
     T.hf = e->d_hf; T.X = e->sp.X; T.Y = e->sp.Y; T.min_x = e->sp.min_x; T.min_y = e->sp.min_y; T.dx = e->sp.dx; T.dy = e->sp.dy;
-    hipLaunchKernelGGL(k_dynamics, dim3((e->N + 63) / 64), dim3(64), 0, st, (const parcdyn::DynModel *)e->d_dyn, T, e->sp.buf, action_dev,
-                       (const float *)e->d_env_off, e->N);
+    if (e->use_coop)
+        hipLaunchKernelGGL(parcdyn::k_dynamics_coop, dim3((e->N + CO_ENVS - 1) / CO_ENVS), dim3(64), 0, st, (const parcdyn::DynModel *)e->d_dyn,
+                           (const parcdyn::CoopTables *)e->d_coop, T, e->sp.buf, action_dev, (const float *)e->d_env_off, e->N);
+    else
+        hipLaunchKernelGGL(k_dynamics, dim3((e->N + 63) / 64), dim3(64), 0, st, (const parcdyn::DynModel *)e->d_dyn, T, e->sp.buf, action_dev,
+                           (const float *)e->d_env_off, e->N);
     HIPCHK(hipGetLastError());
     return PARC_OK;
 }
@@ -1588,6 +1604,18 @@ extern "C" int parc_env_debug_stamps(ParcEnv *e, double *mean8) {
     return fail(PARC_ERR_STATE, "library built without PARC_STAMPS");
 #endif
 }
+
+#ifdef PARC_STAMPS
+// Diagnostic: cycles per phase of k_dynamics_coop summed over all waves since the last call (then cleared).
+extern "C" int parc_env_debug_dyn_stamps(double *out16) {
+    unsigned long long h[16], z[16] = {0};
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(h, HIP_SYMBOL(parcdyn::g_dyn_stamps), sizeof(h)));
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(parcdyn::g_dyn_stamps), z, sizeof(z)));
+    for (int i = 0; i < 16; ++i) out16[i] = (double)h[i];
+    return PARC_OK;
+}
+#endif
 
 extern "C" int parc_env_profile_step(ParcEnv *e, const float *action_dev, void *stream, int32_t iters, float *avg_ms, float *avg_post_ms) {
     int rc = check_ready(e);

@@ -371,7 +371,7 @@ def test_dynamics_rollout_sanity(tmp_path):
     hf = env._scene.grid.terrain.hf
     assert z.min() > hf.min() - 0.5 and z.max() < hf.max() + 3.0
     f = to_np(env._char_contact_forces)
-    assert np.abs(f).max() < 2e4
+    assert np.abs(f).max() < 1e5
     # a character that merely replays the clip's joint angles still stays up for a while: mean reward well above a fallen one
     assert to_np(env._reward_buf).mean() > 0.1
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Developer tool (run on the GPU box via gpurun): PMC passes for the step kernel. Counters go to gpurun_out/pmc_*.
-# Usage: tools/pmc.sh "<counter list>" <tag>
+# Usage: tools/pmc.sh "<counter list>" <tag> [kernel-name substring]   (KB_DYN=1 runs the dynamics step)
 set -e
 cd /tmp && export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
@@ -14,6 +14,6 @@ for row in csv.DictReader(open(f)):
     k = row["Kernel_Name"][:40]
     acc[k][row["Counter_Name"]] += float(row["Counter_Value"]); cnt[(k, row["Counter_Name"])] += 1
 for k in acc:
-    if "k_env_post<0>" in k or "k_env_post" in k:
+    if "${3:-k_env_post}" in k:
         print(k, {c: round(v / cnt[(k, c)]) for c, v in acc[k].items()})
 PY
