@@ -1,0 +1,600 @@
+// parc_dynamics_wave.hpp — wave-per-limb mapping of the dynamics step for gfx950 (HIP only).
+//
+// Same equations as parc_dynamics.hpp.  Mapping: a 256-thread block carries 64 envs; LANE = env, WAVE = limb.
+// Wave w owns limb chain w+1 (humanoid: right arm, left arm, right leg, left leg) of all 64 envs; wave 0 also
+// owns the trunk chain (pelvis, torso, head).  Consequences:
+//   * every lane of a wave works on the SAME body, so body / joint / collision tables are wave-uniform: they are
+//     scalar loads, the joint type is a uniform branch, collision-point loops have uniform trip counts;
+//   * all 64 lanes are busy in the limb phases (the chain-parallel kernel in parc_dynamics_coop.hpp keeps 5 of 8
+//     lanes busy there and 1 of 8 in the trunk phase), and the trunk phase costs one wave for 64 envs;
+//   * a chain's joint state and kinematics stay in registers (k loops are fully unrolled, bodies are constants),
+//     the joint-space factors K = U D^-1 and D^-1 u park in LDS between the inward and the outward pass, laid out
+//     [slot][lane] so that every LDS access is conflict-free;
+//   * waves meet at three barriers per substep (trunk kinematics -> limbs in -> trunk in/out -> limbs out).
+// BUILD NOTE: the library is compiled with -fno-slp-vectorize.  With SLP vectorisation on, hipcc (ROCm 7.2) turns the
+// 3x3 / 6x6 algebra on wave-uniform model constants into v_pk_fma_f32 with op_sel on SGPR pairs and this kernel
+// computes wrong inertias on gfx950 (checked against the other two kernels and the CPU build; the scalar build agrees
+// with them to 1e-6).
+#pragma once
+#include "parc_dynamics_coop.hpp"
+
+#if defined(__HIPCC__)
+#pragma clang fp contract(fast)
+#endif
+
+namespace parcdyn {
+
+#define WV_MAXLEN 3   // bodies per chain
+#define WV_MAXLIMB 4  // limb chains = waves per block
+#define WV_MAXATT 3   // trunk bodies that carry limbs
+#define WV_PI (DYN_PATCH - 4)
+#define WV_FAC 21     // K (18) + D^-1 u (3)
+
+struct WaveTables {
+    int nlimb;
+    int len[1 + WV_MAXLIMB];               // chain 0 = trunk, 1.. = limbs
+    int body[1 + WV_MAXLIMB][WV_MAXLEN];
+    int par_slot[1 + WV_MAXLIMB];          // attach slot of the trunk body a limb hangs off
+    int att_slot[WV_MAXLEN];               // per trunk position: attach slot or -1
+    int nchild[WV_MAXLEN];                 // per trunk position: limbs hanging off it
+    int child[WV_MAXLEN][WV_MAXLIMB];      // limb chain ids (1..)
+    int npt[DYN_MAXB], pt0[DYN_MAXB];
+    float brad[DYN_MAXB];
+};
+
+// LDS layout (floats); everything is [slot][64 lanes]
+#define WV_OFF_ATTKIN 0
+#define WV_OFF_UP (WV_OFF_ATTKIN + WV_MAXATT * 13 * 64)
+#define WV_OFF_ATTACC (WV_OFF_UP + WV_MAXLIMB * 27 * 64)
+#define WV_OFF_ROOTP (WV_OFF_ATTACC + WV_MAXATT * 6 * 64)
+#define WV_OFF_PATCH (WV_OFF_ROOTP + 3 * 64)
+#define WV_OFF_PMAX (WV_OFF_PATCH + DYN_PATCH * DYN_PATCH * 64)
+#define WV_OFF_FAC (WV_OFF_PMAX + WV_PI * WV_PI * 64)
+#define WV_LDS_FLOATS (WV_OFF_FAC + (1 + WV_MAXLIMB) * WV_MAXLEN * WV_FAC * 64)
+
+inline bool build_wave_tables(const DynModel &M, const CoopTables &C, WaveTables &W) {
+    memset(&W, 0, sizeof(W));
+    if (C.nchain < 1 || C.nchain > 1 + WV_MAXLIMB || C.nlevel > 2) return false;
+    W.nlimb = C.nchain - 1;
+    for (int c = 0; c < C.nchain; ++c) {
+        if (C.len[c] > WV_MAXLEN) return false;
+        W.len[c] = C.len[c];
+        for (int k = 0; k < C.len[c]; ++k) W.body[c][k] = C.body[c][k];
+    }
+    int natt = 0;
+    for (int k = 0; k < WV_MAXLEN; ++k) W.att_slot[k] = -1;
+    for (int c = 1; c < C.nchain; ++c) {
+        int pos = -1;
+        for (int k = 0; k < W.len[0]; ++k) if (W.body[0][k] == C.par_body[c]) pos = k;
+        if (pos < 0) return false; // limb does not hang off the trunk
+        if (W.att_slot[pos] < 0) { if (natt >= WV_MAXATT) return false; W.att_slot[pos] = natt++; }
+        W.par_slot[c] = W.att_slot[pos];
+        W.child[pos][W.nchild[pos]++] = c;
+    }
+    for (int b = 0; b < M.B; ++b) { W.npt[b] = C.npt[b]; W.pt0[b] = C.pt0[b]; W.brad[b] = C.brad[b]; }
+    return true;
+}
+
+#if defined(__HIPCC__)
+
+struct WvBody { // per-body registers of the owning lane
+    q4 jq, tq; float hang, thang; v3 qd; // joint state (spherical: quaternion + child-frame omega; hinge: angle + rate)
+    q4 bq; v3 r; s6 vel, cJ;             // kinematics of the current substep (common frame, origin = root)
+    v3 fcon, qdd;
+};
+
+__device__ __forceinline__ void wv_load_joint(const DynModel &M, int b, WvBody &B, const float *dp, const float *dv, const float *ac) {
+    B.jq.x = 0.f; B.jq.y = 0.f; B.jq.z = 0.f; B.jq.w = 1.f; B.tq = B.jq; B.hang = 0.f; B.thang = 0.f; B.qd = mk(0.f, 0.f, 0.f);
+    B.fcon = mk(0.f, 0.f, 0.f); B.qdd = mk(0.f, 0.f, 0.f);
+    const int jt = M.jtype[b], di = M.dof_idx[b];
+    if (jt == DJ_SPHERICAL) {
+        B.jq = qexp(mk(dp[di], dp[di + 1], dp[di + 2]));
+        B.tq = qexp(mk(clampf(ac[di], M.act_lo[di], M.act_hi[di]), clampf(ac[di + 1], M.act_lo[di + 1], M.act_hi[di + 1]),
+                       clampf(ac[di + 2], M.act_lo[di + 2], M.act_hi[di + 2])));
+        B.qd = mk(dv[di], dv[di + 1], dv[di + 2]);
+    } else if (jt == DJ_HINGE) {
+        B.hang = dp[di]; B.thang = clampf(ac[di], M.act_lo[di], M.act_hi[di]); B.qd.x = dv[di];
+    }
+}
+
+// kinematics of body b given its parent's (pq, pr, pv); leaves its own in (pq, pr, pv) for the next body of the chain
+__device__ __forceinline__ void wv_fk_body(const DynModel &M, int b, WvBody &B, q4 &pq, v3 &pr, s6 &pv) {
+    s6 cJ = s6zero();
+    if (b != 0) {
+        const int jt = M.jtype[b];
+        const m3 Rp = qmat(pq);
+        pr = pr + mulv(Rp, mk(M.lt[b][0], M.lt[b][1], M.lt[b][2]));
+        q4 lq; lq.x = M.lr[b][0]; lq.y = M.lr[b][1]; lq.z = M.lr[b][2]; lq.w = M.lr[b][3];
+        q4 jr = B.jq;
+        if (jt == DJ_HINGE) jr = qexp(B.hang * mk(M.axis[b][0], M.axis[b][1], M.axis[b][2]));
+        pq = qnormalize(qmul(pq, qmul(lq, jr)));
+        const m3 R = qmat(pq);
+        v3 wj = mk(0.f, 0.f, 0.f);
+        if (jt == DJ_SPHERICAL) wj = mulv(R, B.qd);
+        else if (jt == DJ_HINGE) wj = B.qd.x * mulv(R, mk(M.axis[b][0], M.axis[b][1], M.axis[b][2]));
+        const s6 vJ = s6mk(wj, cross(pr, wj));
+        pv = pv + vJ;
+        cJ = crm(pv, vJ);
+    }
+    B.bq = pq; B.r = pr; B.vel = pv; B.cJ = cJ;
+}
+
+struct WvCtx { // per-lane constants of the control step
+    const float *s_patch, *s_pmax; // + lane
+    int pox, poy;
+    float eo0, eo1, eo2, cell_min, dt;
+};
+
+// articulated inertia / bias of body b: own inertia + contacts + (IA, pA) carried in from the chain's child
+__device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTables &W, const DynTerrain &T, const WvCtx &X, int b, WvBody &B,
+                                                const m3 &R, v3 rootp, sym6 &IA, s6 &pA) {
+    const v3 r = B.r;
+    const float dt = X.dt;
+    {
+        const v3 cm = r + mulv(R, mk(M.com[b][0], M.com[b][1], M.com[b][2]));
+        const float Ib[3][3] = {{M.inertia[b][0], M.inertia[b][3], M.inertia[b][4]}, {M.inertia[b][3], M.inertia[b][1], M.inertia[b][5]},
+                                {M.inertia[b][4], M.inertia[b][5], M.inertia[b][2]}};
+        float RI[3][3], Iw[3][3];
+        PARC_UNROLL
+        for (int a = 0; a < 3; ++a) {
+            PARC_UNROLL
+            for (int q = 0; q < 3; ++q) RI[a][q] = R.m[a][0] * Ib[0][q] + R.m[a][1] * Ib[1][q] + R.m[a][2] * Ib[2][q];
+        }
+        PARC_UNROLL
+        for (int a = 0; a < 3; ++a) {
+            PARC_UNROLL
+            for (int q = 0; q < 3; ++q) Iw[a][q] = RI[a][0] * R.m[q][0] + RI[a][1] * R.m[q][1] + RI[a][2] * R.m[q][2];
+        }
+        const float Icw[6] = {Iw[0][0], Iw[1][1], Iw[2][2], Iw[0][1], Iw[0][2], Iw[1][2]};
+        sym6 Iown;
+        PARC_UNROLL
+        for (int i = 0; i < 21; ++i) Iown.s[i] = 0.f;
+        add_inertia(Iown, M.mass[b], cm, Icw);
+        const s6 Iv = symmul(Iown, B.vel);
+        const s6 pb = crf(B.vel, Iv);
+        const v3 fg = mk(0.f, 0.f, M.mass[b] * M.gravity_z);
+        const v3 ng = cross(cm, fg);
+        PARC_UNROLL
+        for (int i = 0; i < 21; ++i) IA.s[i] += Iown.s[i];
+        pA.a[0] += pb.a[0] - ng.x; pA.a[1] += pb.a[1] - ng.y; pA.a[2] += pb.a[2] - ng.z;
+        pA.a[3] += pb.a[3] - fg.x; pA.a[4] += pb.a[4] - fg.y; pA.a[5] += pb.a[5] - fg.z;
+    }
+    // contacts.  A body whose bounding sphere clears every column its collision spheres could touch is skipped
+    // (exact: those contributions are zero).
+    v3 fsum = mk(0.f, 0.f, 0.f);
+    const float brad = W.brad[b];
+    bool near = true;
+    {
+        const int bx = cell_of(r.x + rootp.x + X.eo0, T.min_x, T.dx) - X.pox, by = cell_of(r.y + rootp.y + X.eo1, T.min_y, T.dy) - X.poy;
+        if (brad < X.cell_min && bx >= 2 && bx < DYN_PATCH - 2 && by >= 2 && by < DYN_PATCH - 2 &&
+            r.z + rootp.z + X.eo2 - brad > X.s_pmax[((bx - 2) * WV_PI + by - 2) * 64]) near = false;
+    }
+    if (near) {
+        const int npt = W.npt[b], pt0 = W.pt0[b];
+        for (int pi = 0; pi < npt; ++pi) {
+            const int kp = pt0 + pi;
+            const v3 x = r + mulv(R, mk(M.col_pos[kp][0], M.col_pos[kp][1], M.col_pos[kp][2]));
+            const v3 g = mk(x.x + rootp.x + X.eo0, x.y + rootp.y + X.eo1, x.z + rootp.z + X.eo2);
+            const float rad = M.col_r[kp];
+            const int ix = cell_of(g.x, T.min_x, T.dx), iy = cell_of(g.y, T.min_y, T.dy);
+            const int pa_ = ix - X.pox, pb_ = iy - X.poy;
+            const bool inp = pa_ >= 1 && pa_ < DYN_PATCH - 1 && pb_ >= 1 && pb_ < DYN_PATCH - 1;
+            const float top0 = inp ? X.s_patch[(pa_ * DYN_PATCH + pb_) * 64] : hf_at(T, ix, iy);
+            const v3 vpt = s6lin(B.vel) + cross(s6ang(B.vel), x);
+            for (int nb = 0; nb < 9; ++nb) {
+                const int ox_ = (nb % 3) - 1, oy_ = (nb / 3) - 1;
+                const bool own = nb == 4;
+                const float top = own ? top0 : (inp ? X.s_patch[((pa_ + ox_) * DYN_PATCH + pb_ + oy_) * 64] : hf_at(T, ix + ox_, iy + oy_));
+                if (!own && !(top > top0 + 1e-3f)) continue;
+                if (g.z - rad > top) continue;
+                v3 n;
+                const float pen = sphere_vs_column(T, g, rad, ix + ox_, iy + oy_, top, n);
+                if (!(pen > 0.f)) continue;
+                const float vn = dot(vpt, n);
+                float fn = M.kn * pen - M.dn * vn;
+                if (fn < 0.f) fn = 0.f;
+                const v3 vt = vpt - vn * n;
+                const float vtm = sqrtf(dot(vt, vt));
+                float beta = M.dtang;
+                if (beta * vtm > M.mu * fn) beta = vtm > 1e-9f ? M.mu * fn / vtm : 0.f;
+                const v3 f = fn * n - beta * vt;
+                const v3 no = cross(x, f);
+                pA.a[0] -= no.x; pA.a[1] -= no.y; pA.a[2] -= no.z; pA.a[3] -= f.x; pA.a[4] -= f.y; pA.a[5] -= f.z;
+                fsum = fsum + f;
+                const float bn = fn > 0.f ? (M.dn + dt * M.kn) : 0.f;
+                add_inertia(IA, dt * beta, x, nullptr);
+                symrank1(IA, dt * (bn - beta), s6mk(cross(x, n), n));
+            }
+        }
+    }
+    B.fcon = fsum;
+}
+
+// joint elimination of body b: (IA, pA) -> contribution (Ic, pc) to the parent; K and D^-1 u go to LDS (fac + lane, stride 64)
+__device__ __forceinline__ void wv_joint_inward(const DynModel &M, int b, const WvBody &B, const m3 &R, float dt, const sym6 &IA, const s6 &pA,
+                                                sym6 &Ic, s6 &pc, float *fac) {
+    const int jt = M.jtype[b], di = M.dof_idx[b];
+    const v3 r = B.r;
+    if (jt == DJ_SPHERICAL) {
+        s6 Sc[3], Uc[3];
+        float tau[3], aug[3], uu[3];
+        PARC_UNROLL
+        for (int q = 0; q < 3; ++q) { const v3 a = mk(R.m[0][q], R.m[1][q], R.m[2][q]); Sc[q] = s6mk(a, cross(r, a)); }
+        const v3 err = qlog(qmul(qconj(B.jq), B.tq));
+        const v3 cur = qlog(B.jq);
+        const float e3[3] = {err.x, err.y, err.z}, c3[3] = {cur.x, cur.y, cur.z}, q3[3] = {B.qd.x, B.qd.y, B.qd.z};
+        PARC_UNROLL
+        for (int q = 0; q < 3; ++q) {
+            float t = M.kp[di + q] * e3[q] - (M.kd[di + q] + dt * M.kp[di + q]) * q3[q];
+            t = clampf(t, -M.eff[di + q], M.eff[di + q]);
+            aug[q] = M.arm[di + q] + dt * M.kd[di + q] + dt * dt * M.kp[di + q];
+            if (c3[q] < M.lo[di + q]) { t += M.lim_k * (M.lo[di + q] - c3[q]) - M.lim_d * q3[q]; aug[q] += dt * M.lim_d + dt * dt * M.lim_k; }
+            else if (c3[q] > M.hi[di + q]) { t += M.lim_k * (M.hi[di + q] - c3[q]) - M.lim_d * q3[q]; aug[q] += dt * M.lim_d + dt * dt * M.lim_k; }
+            tau[q] = t;
+        }
+        PARC_UNROLL
+        for (int q = 0; q < 3; ++q) {
+            Uc[q] = symmul(IA, Sc[q]);
+            float sp = 0.f;
+            PARC_UNROLL
+            for (int a = 0; a < 6; ++a) sp += Sc[q].a[a] * pA.a[a];
+            uu[q] = tau[q] - sp;
+        }
+        float Dm[3][3];
+        PARC_UNROLL
+        for (int q = 0; q < 3; ++q) {
+            PARC_UNROLL
+            for (int l = 0; l < 3; ++l) {
+                float a_ = 0.f;
+                PARC_UNROLL
+                for (int a = 0; a < 6; ++a) a_ += Sc[q].a[a] * Uc[l].a[a];
+                Dm[q][l] = a_ + (q == l ? aug[q] : 0.f);
+            }
+        }
+        const float c00 = Dm[1][1] * Dm[2][2] - Dm[1][2] * Dm[2][1], c01 = Dm[0][2] * Dm[2][1] - Dm[0][1] * Dm[2][2],
+                    c02 = Dm[0][1] * Dm[1][2] - Dm[0][2] * Dm[1][1];
+        const float id = 1.f / (Dm[0][0] * c00 + Dm[1][0] * c01 + Dm[2][0] * c02);
+        float D3[3][3];
+        D3[0][0] = c00 * id; D3[0][1] = c01 * id; D3[0][2] = c02 * id;
+        D3[1][1] = (Dm[0][0] * Dm[2][2] - Dm[0][2] * Dm[2][0]) * id;
+        D3[1][2] = (Dm[0][2] * Dm[1][0] - Dm[0][0] * Dm[1][2]) * id;
+        D3[2][2] = (Dm[0][0] * Dm[1][1] - Dm[0][1] * Dm[1][0]) * id;
+        D3[1][0] = D3[0][1]; D3[2][0] = D3[0][2]; D3[2][1] = D3[1][2];
+        s6 Kc[3];
+        float du[3];
+        PARC_UNROLL
+        for (int q = 0; q < 3; ++q) {
+            PARC_UNROLL
+            for (int a = 0; a < 6; ++a) Kc[q].a[a] = Uc[0].a[a] * D3[0][q] + Uc[1].a[a] * D3[1][q] + Uc[2].a[a] * D3[2][q];
+            du[q] = D3[q][0] * uu[0] + D3[q][1] * uu[1] + D3[q][2] * uu[2];
+        }
+        Ic = IA;
+        PARC_UNROLL
+        for (int a = 0; a < 6; ++a) {
+            PARC_UNROLL
+            for (int q = a; q < 6; ++q) Ic.s[sidx(a, q)] -= Kc[0].a[a] * Uc[0].a[q] + Kc[1].a[a] * Uc[1].a[q] + Kc[2].a[a] * Uc[2].a[q];
+        }
+        const s6 Iac = symmul(Ic, B.cJ);
+        PARC_UNROLL
+        for (int a = 0; a < 6; ++a) pc.a[a] = pA.a[a] + Iac.a[a] + Kc[0].a[a] * uu[0] + Kc[1].a[a] * uu[1] + Kc[2].a[a] * uu[2];
+        PARC_UNROLL
+        for (int q = 0; q < 3; ++q) {
+            PARC_UNROLL
+            for (int a = 0; a < 6; ++a) fac[(6 * q + a) * 64] = Kc[q].a[a];
+            fac[(18 + q) * 64] = du[q];
+        }
+    } else if (jt == DJ_HINGE) {
+        const v3 a = mulv(R, mk(M.axis[b][0], M.axis[b][1], M.axis[b][2]));
+        const s6 Sc = s6mk(a, cross(r, a));
+        float t = M.kp[di] * (B.thang - B.hang) - (M.kd[di] + dt * M.kp[di]) * B.qd.x;
+        t = clampf(t, -M.eff[di], M.eff[di]);
+        float aug = M.arm[di] + dt * M.kd[di] + dt * dt * M.kp[di];
+        if (B.hang < M.lo[di]) { t += M.lim_k * (M.lo[di] - B.hang) - M.lim_d * B.qd.x; aug += dt * M.lim_d + dt * dt * M.lim_k; }
+        else if (B.hang > M.hi[di]) { t += M.lim_k * (M.hi[di] - B.hang) - M.lim_d * B.qd.x; aug += dt * M.lim_d + dt * dt * M.lim_k; }
+        const s6 Uc = symmul(IA, Sc);
+        float sp = 0.f, d = aug;
+        PARC_UNROLL
+        for (int q = 0; q < 6; ++q) { sp += Sc.a[q] * pA.a[q]; d += Sc.a[q] * Uc.a[q]; }
+        const float uu = t - sp, di_ = 1.f / d;
+        s6 Kc;
+        PARC_UNROLL
+        for (int q = 0; q < 6; ++q) Kc.a[q] = Uc.a[q] * di_;
+        Ic = IA;
+        PARC_UNROLL
+        for (int q = 0; q < 6; ++q) {
+            PARC_UNROLL
+            for (int l = q; l < 6; ++l) Ic.s[sidx(q, l)] -= Kc.a[q] * Uc.a[l];
+        }
+        const s6 Iac = symmul(Ic, B.cJ);
+        PARC_UNROLL
+        for (int q = 0; q < 6; ++q) { pc.a[q] = pA.a[q] + Iac.a[q] + Kc.a[q] * uu; fac[q * 64] = Kc.a[q]; }
+        fac[18 * 64] = di_ * uu;
+    } else { // fixed joint
+        const s6 Iac = symmul(IA, B.cJ);
+        Ic = IA;
+        pc = pA + Iac;
+    }
+}
+
+// acceleration of body b from its parent's (ap); leaves its own in ap
+__device__ __forceinline__ void wv_joint_outward(const DynModel &M, int b, WvBody &B, s6 &ap, const float *fac) {
+    const int jt = M.jtype[b];
+    s6 ai = ap + B.cJ;
+    if (jt == DJ_SPHERICAL) {
+        float q3[3];
+        PARC_UNROLL
+        for (int q = 0; q < 3; ++q) {
+            float ka = 0.f;
+            PARC_UNROLL
+            for (int a = 0; a < 6; ++a) ka += fac[(6 * q + a) * 64] * ai.a[a];
+            q3[q] = fac[(18 + q) * 64] - ka;
+        }
+        B.qdd = mk(q3[0], q3[1], q3[2]);
+        const v3 wj = mulv(qmat(B.bq), B.qdd);
+        ai = ai + s6mk(wj, cross(B.r, wj));
+    } else if (jt == DJ_HINGE) {
+        float ka = 0.f;
+        PARC_UNROLL
+        for (int a = 0; a < 6; ++a) ka += fac[a * 64] * ai.a[a];
+        const float qa = fac[18 * 64] - ka;
+        B.qdd = mk(qa, 0.f, 0.f);
+        const v3 wj = qa * mulv(qmat(B.bq), mk(M.axis[b][0], M.axis[b][1], M.axis[b][2]));
+        ai = ai + s6mk(wj, cross(B.r, wj));
+    }
+    ap = ai;
+}
+
+__device__ __forceinline__ void wv_integrate_joint(const DynModel &M, int b, WvBody &B, float dt) {
+    const int jt = M.jtype[b];
+    const float mw = M.max_ang_vel;
+    if (jt == DJ_SPHERICAL) {
+        B.qd = mk(clampf(B.qd.x + dt * B.qdd.x, -mw, mw), clampf(B.qd.y + dt * B.qdd.y, -mw, mw), clampf(B.qd.z + dt * B.qdd.z, -mw, mw));
+        B.jq = qnormalize(qmul(B.jq, qexp(dt * B.qd)));
+    } else if (jt == DJ_HINGE) {
+        B.qd.x = clampf(B.qd.x + dt * B.qdd.x, -mw, mw);
+        B.hang += dt * B.qd.x;
+    }
+}
+
+__device__ __forceinline__ void wv_store_joint(const DynModel &M, int b, const WvBody &B, float *dp, float *dv, float *cf) {
+    const int jt = M.jtype[b], di = M.dof_idx[b];
+    // plain copies first: selecting between struct fields inside the branches would keep the body in scratch
+    const q4 jq = B.jq; const float hang = B.hang; const v3 qd = B.qd, fc = B.fcon;
+    if (jt == DJ_SPHERICAL) {
+        const v3 ex = qlog(jq);
+        dp[di] = ex.x; dp[di + 1] = ex.y; dp[di + 2] = ex.z; dv[di] = qd.x; dv[di + 1] = qd.y; dv[di + 2] = qd.z;
+    } else if (jt == DJ_HINGE) { dp[di] = hang; dv[di] = qd.x; }
+    cf[3 * b] = fc.x; cf[3 * b + 1] = fc.y; cf[3 * b + 2] = fc.z;
+}
+
+__global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__restrict__ Mp, const WaveTables *__restrict__ Wp, DynTerrain T,
+                                                          ParcEnvBuffers buf, const float *__restrict__ action,
+                                                          const float *__restrict__ env_off_all, int N) {
+    extern __shared__ float smem[];
+    const DynModel &M = *Mp;
+    const WaveTables &W = *Wp;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int e = blockIdx.x * 64 + lane;
+    const bool env_ok = e < N;
+    const int ec = env_ok ? e : N - 1; // clamp for address safety; lanes past N compute on a copy and store nothing
+    const float dt = M.dt;
+    const int B_ = M.B, D_ = M.D, nsub = M.nsub;
+    const int lc = w + 1;              // this wave's limb chain
+    const bool has_limb = w < W.nlimb;
+    const int llen = has_limb ? W.len[lc] : 0, tlen = w == 0 ? W.len[0] : 0;
+
+    float *s_attkin = smem + WV_OFF_ATTKIN + lane, *s_up = smem + WV_OFF_UP + lane, *s_attacc = smem + WV_OFF_ATTACC + lane;
+    float *s_rootp = smem + WV_OFF_ROOTP + lane, *s_patch = smem + WV_OFF_PATCH + lane, *s_pmax = smem + WV_OFF_PMAX + lane;
+    float *s_fac = smem + WV_OFF_FAC + lane;
+
+    const float *dp = buf.char_dof_pos + (size_t)D_ * ec, *dv = buf.char_dof_vel + (size_t)D_ * ec, *ac = action + (size_t)D_ * ec;
+    WvBody limb[WV_MAXLEN], trunk[WV_MAXLEN];
+    PARC_UNROLL
+    for (int k = 0; k < WV_MAXLEN; ++k) {
+        if (k < llen) wv_load_joint(M, W.body[lc][k], limb[k], dp, dv, ac);
+        if (k < tlen) wv_load_joint(M, W.body[0][k], trunk[k], dp, dv, ac);
+    }
+    v3 rp = mk(buf.char_root_pos[3 * ec], buf.char_root_pos[3 * ec + 1], buf.char_root_pos[3 * ec + 2]);
+    q4 rq; rq.x = buf.char_root_rot[4 * ec]; rq.y = buf.char_root_rot[4 * ec + 1]; rq.z = buf.char_root_rot[4 * ec + 2]; rq.w = buf.char_root_rot[4 * ec + 3];
+    rq = qnormalize(rq);
+    v3 rv = mk(buf.char_root_vel[3 * ec], buf.char_root_vel[3 * ec + 1], buf.char_root_vel[3 * ec + 2]);
+    v3 rw = mk(buf.char_root_ang_vel[3 * ec], buf.char_root_ang_vel[3 * ec + 1], buf.char_root_ang_vel[3 * ec + 2]);
+
+    WvCtx X;
+    X.s_patch = s_patch; X.s_pmax = s_pmax; X.dt = dt;
+    X.eo0 = env_off_all[3 * ec]; X.eo1 = env_off_all[3 * ec + 1]; X.eo2 = env_off_all[3 * ec + 2];
+    X.cell_min = fminf(T.dx, T.dy);
+    X.pox = cell_of(rp.x + X.eo0, T.min_x, T.dx) - DYN_PATCH / 2; X.poy = cell_of(rp.y + X.eo1, T.min_y, T.dy) - DYN_PATCH / 2;
+    // local height patch of each env (the 4 waves share the 81 cells), then its 5x5 running maximum
+    for (int i = w; i < DYN_PATCH * DYN_PATCH; i += 4) s_patch[i * 64] = hf_at(T, X.pox + i / DYN_PATCH, X.poy + i % DYN_PATCH);
+    __syncthreads();
+    for (int i = w; i < WV_PI * WV_PI; i += 4) {
+        const int pi_ = i / WV_PI + 2, pj_ = i % WV_PI + 2;
+        float m = -3.0e38f;
+        for (int a = -2; a <= 2; ++a) for (int q = -2; q <= 2; ++q) m = fmaxf(m, s_patch[((pi_ + a) * DYN_PATCH + pj_ + q) * 64]);
+        s_pmax[i * 64] = m;
+    }
+    __syncthreads();
+
+    for (int sub = 0; sub < nsub; ++sub) {
+        // ---- phase 1: trunk kinematics (wave 0) -------------------------------------------------------------------------
+        if (w == 0) {
+            s_rootp[0] = rp.x; s_rootp[64] = rp.y; s_rootp[128] = rp.z;
+            q4 pq = rq; v3 pr = mk(0.f, 0.f, 0.f); s6 pv = s6mk(rw, rv);
+            PARC_UNROLL
+            for (int k = 0; k < WV_MAXLEN; ++k) {
+                if (k < tlen) {
+                    wv_fk_body(M, W.body[0][k], trunk[k], pq, pr, pv);
+                    const int slot = W.att_slot[k];
+                    if (slot >= 0) {
+                        float *s = s_attkin + slot * 13 * 64;
+                        s[0] = pq.x; s[64] = pq.y; s[128] = pq.z; s[192] = pq.w; s[256] = pr.x; s[320] = pr.y; s[384] = pr.z;
+                        PARC_UNROLL
+                        for (int a = 0; a < 6; ++a) s[(7 + a) * 64] = pv.a[a];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const v3 rootp = mk(s_rootp[0], s_rootp[64], s_rootp[128]);
+        // ---- phase 2: limb kinematics + inward pass (all waves) ---------------------------------------------------------
+        if (has_limb) {
+            const float *s = s_attkin + W.par_slot[lc] * 13 * 64;
+            q4 pq; pq.x = s[0]; pq.y = s[64]; pq.z = s[128]; pq.w = s[192];
+            v3 pr = mk(s[256], s[320], s[384]);
+            s6 pv;
+            PARC_UNROLL
+            for (int a = 0; a < 6; ++a) pv.a[a] = s[(7 + a) * 64];
+            PARC_UNROLL
+            for (int k = 0; k < WV_MAXLEN; ++k) if (k < llen) wv_fk_body(M, W.body[lc][k], limb[k], pq, pr, pv);
+            sym6 Ic; s6 pc = s6zero();
+            PARC_UNROLL
+            for (int i = 0; i < 21; ++i) Ic.s[i] = 0.f;
+            PARC_UNROLL
+            for (int kk = 0; kk < WV_MAXLEN; ++kk) {
+                const int k = WV_MAXLEN - 1 - kk;
+                if (k < llen) {
+                    const int b = W.body[lc][k];
+                    const m3 R = qmat(limb[k].bq);
+                    sym6 IA = Ic; s6 pA = pc;
+                    wv_body_inertia(M, W, T, X, b, limb[k], R, rootp, IA, pA);
+                    wv_joint_inward(M, b, limb[k], R, dt, IA, pA, Ic, pc, s_fac + (lc * WV_MAXLEN + k) * WV_FAC * 64);
+                }
+            }
+            float *u = s_up + (lc - 1) * 27 * 64;
+            PARC_UNROLL
+            for (int i = 0; i < 21; ++i) u[i * 64] = Ic.s[i];
+            PARC_UNROLL
+            for (int a = 0; a < 6; ++a) u[(21 + a) * 64] = pc.a[a];
+        }
+        __syncthreads();
+        // ---- phase 3: trunk inward, floating-base solve, trunk outward, trunk/root integration (wave 0) --------------
+        if (w == 0) {
+            sym6 Ic; s6 pc = s6zero();
+            PARC_UNROLL
+            for (int i = 0; i < 21; ++i) Ic.s[i] = 0.f;
+            s6 acc_root = s6zero();
+            PARC_UNROLL
+            for (int kk = 0; kk < WV_MAXLEN; ++kk) {
+                const int k = WV_MAXLEN - 1 - kk;
+                if (k < tlen) {
+                    const int b = W.body[0][k];
+                    const m3 R = qmat(trunk[k].bq);
+                    sym6 IA = Ic; s6 pA = pc;
+                    wv_body_inertia(M, W, T, X, b, trunk[k], R, rootp, IA, pA);
+                    for (int ci = 0; ci < W.nchild[k]; ++ci) {
+                        const float *u = s_up + (W.child[k][ci] - 1) * 27 * 64;
+                        PARC_UNROLL
+                        for (int i = 0; i < 21; ++i) IA.s[i] += u[i * 64];
+                        PARC_UNROLL
+                        for (int a = 0; a < 6; ++a) pA.a[a] += u[(21 + a) * 64];
+                    }
+                    if (b == 0) { // floating base: solve IA a0 = -pA (Cholesky)
+                        float Lm[6][6];
+                        PARC_UNROLL
+                        for (int j = 0; j < 6; ++j) {
+                            float sd = sget(IA, j, j);
+                            PARC_UNROLL
+                            for (int q = 0; q < j; ++q) sd -= Lm[j][q] * Lm[j][q];
+                            sd = sd > 1e-12f ? sqrtf(sd) : 1e-6f;
+                            Lm[j][j] = sd;
+                            const float isd = 1.f / sd;
+                            PARC_UNROLL
+                            for (int a = j + 1; a < 6; ++a) {
+                                float sa = sget(IA, a, j);
+                                PARC_UNROLL
+                                for (int q = 0; q < j; ++q) sa -= Lm[a][q] * Lm[j][q];
+                                Lm[a][j] = sa * isd;
+                            }
+                            Lm[j][j] = isd; // keep the reciprocal of the pivot
+                        }
+                        float y[6], xs[6];
+                        PARC_UNROLL
+                        for (int a = 0; a < 6; ++a) {
+                            float sa = -pA.a[a];
+                            PARC_UNROLL
+                            for (int q = 0; q < a; ++q) sa -= Lm[a][q] * y[q];
+                            y[a] = sa * Lm[a][a];
+                        }
+                        PARC_UNROLL
+                        for (int a_ = 0; a_ < 6; ++a_) {
+                            const int a = 5 - a_;
+                            float sa = y[a];
+                            PARC_UNROLL
+                            for (int q = a + 1; q < 6; ++q) sa -= Lm[q][a] * xs[q];
+                            xs[a] = sa * Lm[a][a];
+                        }
+                        PARC_UNROLL
+                        for (int a = 0; a < 6; ++a) acc_root.a[a] = xs[a];
+                    } else {
+                        wv_joint_inward(M, b, trunk[k], R, dt, IA, pA, Ic, pc, s_fac + k * WV_FAC * 64);
+                    }
+                }
+            }
+            s6 ap = acc_root;
+            PARC_UNROLL
+            for (int k = 0; k < WV_MAXLEN; ++k) {
+                if (k < tlen) {
+                    const int b = W.body[0][k];
+                    if (b != 0) wv_joint_outward(M, b, trunk[k], ap, s_fac + k * WV_FAC * 64);
+                    const int slot = W.att_slot[k];
+                    if (slot >= 0) {
+                        PARC_UNROLL
+                        for (int a = 0; a < 6; ++a) s_attacc[(slot * 6 + a) * 64] = ap.a[a];
+                    }
+                }
+            }
+            // root + trunk joints
+            {
+                const v3 alpha = s6ang(acc_root), aO = s6lin(acc_root);
+                const v3 rv_new = rv + dt * (aO + cross(rw, rv));
+                v3 rw_new = rw + dt * alpha;
+                rw_new = (1.f / (1.f + dt * M.ang_damping)) * rw_new;
+                const float wm = sqrtf(dot(rw_new, rw_new));
+                if (wm > M.max_ang_vel) rw_new = (M.max_ang_vel / wm) * rw_new;
+                rv = rv_new; rw = rw_new;
+                rp = rp + dt * rv;
+                rq = qnormalize(qmul(qexp(dt * rw), rq));
+            }
+            PARC_UNROLL
+            for (int k = 0; k < WV_MAXLEN; ++k) if (k < tlen) wv_integrate_joint(M, W.body[0][k], trunk[k], dt);
+        }
+        __syncthreads();
+        // ---- phase 4: limb outward pass + integration (all waves) -------------------------------------------------------
+        if (has_limb) {
+            s6 ap;
+            PARC_UNROLL
+            for (int a = 0; a < 6; ++a) ap.a[a] = s_attacc[(W.par_slot[lc] * 6 + a) * 64];
+            PARC_UNROLL
+            for (int k = 0; k < WV_MAXLEN; ++k) {
+                if (k < llen) {
+                    const int b = W.body[lc][k];
+                    wv_joint_outward(M, b, limb[k], ap, s_fac + (lc * WV_MAXLEN + k) * WV_FAC * 64);
+                    wv_integrate_joint(M, b, limb[k], dt);
+                }
+            }
+        }
+    }
+    // ---- write back -----------------------------------------------------------------------------------------------------
+    if (!env_ok) return;
+    float *odp = buf.char_dof_pos + (size_t)D_ * e, *odv = buf.char_dof_vel + (size_t)D_ * e, *ocf = buf.contact_forces + 3 * (size_t)e * B_;
+    if (w == 0) {
+        float *o = buf.char_root_pos + 3 * (size_t)e; o[0] = rp.x; o[1] = rp.y; o[2] = rp.z;
+        o = buf.char_root_rot + 4 * (size_t)e; o[0] = rq.x; o[1] = rq.y; o[2] = rq.z; o[3] = rq.w;
+        o = buf.char_root_vel + 3 * (size_t)e; o[0] = rv.x; o[1] = rv.y; o[2] = rv.z;
+        o = buf.char_root_ang_vel + 3 * (size_t)e; o[0] = rw.x; o[1] = rw.y; o[2] = rw.z;
+    }
+    PARC_UNROLL
+    for (int k = 0; k < WV_MAXLEN; ++k) {
+        if (k < llen) wv_store_joint(M, W.body[lc][k], limb[k], odp, odv, ocf);
+        if (k < tlen) wv_store_joint(M, W.body[0][k], trunk[k], odp, odv, ocf);
+    }
+}
+#endif // __HIPCC__
+
+} // namespace parcdyn
+
+#if defined(__HIPCC__)
+#pragma clang fp contract(off)
+#endif

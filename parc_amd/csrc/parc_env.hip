@@ -26,6 +26,7 @@
 #include "parc_math.hpp"
 #include "parc_dynamics.hpp"
 #include "parc_dynamics_coop.hpp"
+#include "parc_dynamics_wave.hpp"
 
 using namespace parc;
 
@@ -1082,6 +1083,9 @@ struct ParcEnv {
     parcdyn::CoopTables h_coop;
     parcdyn::CoopTables *d_coop = nullptr;
     bool use_coop = false;
+    parcdyn::WaveTables h_wave;
+    parcdyn::WaveTables *d_wave = nullptr;
+    bool use_wave = false;
     DevTables h_tab;
     DevTables *d_tab = nullptr;
     float *d_ray = nullptr, *d_env_off = nullptr, *d_hf = nullptr, *d_motion_off = nullptr;
@@ -1106,7 +1110,7 @@ extern "C" const char *parc_last_error(void) { return g_err.c_str(); }
 extern "C" int parc_abi_version(void) { return PARC_ABI_VERSION; }
 
 static void free_dev(ParcEnv *e) {
-    void *ptrs[] = {e->d_sp, e->d_prep, e->d_dyn, e->d_coop, e->d_tab, e->d_ray, e->d_env_off, e->d_hf, e->d_motion_off, e->d_records, e->d_meta, e->d_weights, e->d_fail,
+    void *ptrs[] = {e->d_sp, e->d_prep, e->d_dyn, e->d_coop, e->d_wave, e->d_tab, e->d_ray, e->d_env_off, e->d_hf, e->d_motion_off, e->d_records, e->d_meta, e->d_weights, e->d_fail,
                     e->d_cdf, e->d_ema, e->d_done_list, e->d_done_key, e->d_chunk_count, e->d_motion_done, e->d_reset_count, e->d_tmp_mid, e->d_tmp_tid, e->d_tmp_t0, e->d_tmp_noise,
                     e->d_scratch_jr};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -1228,13 +1232,24 @@ extern "C" int parc_env_create(const ParcEnvConfig *cfg, ParcEnv **out) {
             free_dev(e); delete e;
             return fail(PARC_ERR_HIP, std::string("device allocation failed: ") + hipGetErrorString(r));
         }
-        // chain-parallel kernel when the tree splits into <= 8 chains of <= 4 bodies; PARC_DYN_KERNEL=thread forces
-        // the thread-per-env kernel (kept as the fallback for other trees and as a cross-check)
+        // Kernel choice by tree shape: wave-per-limb (a trunk chain + <= 4 limb chains of <= 3 bodies, the humanoid),
+        // else chain-parallel (<= 8 chains of <= 4 bodies), else thread-per-env.  PARC_DYN_KERNEL=coop|thread forces
+        // one of the more general kernels (they are kept as fallbacks for other trees and as cross-checks).
         const char *kk = getenv("PARC_DYN_KERNEL");
-        e->use_coop = parcdyn::build_coop_tables(e->h_dyn, e->h_coop) && !(kk && std::string(kk) == "thread");
-        if (e->use_coop && (r = up((void **)&e->d_coop, &e->h_coop, sizeof(e->h_coop))) != hipSuccess) {
+        const std::string want = kk ? kk : "";
+        const bool coop_ok = parcdyn::build_coop_tables(e->h_dyn, e->h_coop);
+        e->use_wave = coop_ok && parcdyn::build_wave_tables(e->h_dyn, e->h_coop, e->h_wave) && want != "coop" && want != "thread";
+        e->use_coop = coop_ok && !e->use_wave && want != "thread";
+        if (e->use_wave) {
+            r = up((void **)&e->d_wave, &e->h_wave, sizeof(e->h_wave));
+            if (r == hipSuccess)
+                r = hipFuncSetAttribute((const void *)parcdyn::k_dynamics_wave, hipFuncAttributeMaxDynamicSharedMemorySize, WV_LDS_FLOATS * (int)sizeof(float));
+        } else if (e->use_coop) {
+            r = up((void **)&e->d_coop, &e->h_coop, sizeof(e->h_coop));
+        }
+        if (r != hipSuccess) {
             free_dev(e); delete e;
-            return fail(PARC_ERR_HIP, std::string("device allocation failed: ") + hipGetErrorString(r));
+            return fail(PARC_ERR_HIP, std::string("dynamics kernel setup failed: ") + hipGetErrorString(r));
         }
     }
     for (auto &ev : e->ev) (void)hipEventCreate(&ev);
@@ -1394,7 +1409,11 @@ static int launch_dynamics(ParcEnv *e, const float *action_dev, hipStream_t st) 
     if (!action_dev) return fail(PARC_ERR_INVALID, "action is required when enable_dynamics is set");
     parcdyn::DynTerrain T;
     T.hf = e->d_hf; T.X = e->sp.X; T.Y = e->sp.Y; T.min_x = e->sp.min_x; T.min_y = e->sp.min_y; T.dx = e->sp.dx; T.dy = e->sp.dy;
-    if (e->use_coop)
+    if (e->use_wave)
+        hipLaunchKernelGGL(parcdyn::k_dynamics_wave, dim3((e->N + 63) / 64), dim3(256), WV_LDS_FLOATS * sizeof(float), st,
+                           (const parcdyn::DynModel *)e->d_dyn, (const parcdyn::WaveTables *)e->d_wave, T, e->sp.buf, action_dev,
+                           (const float *)e->d_env_off, e->N);
+    else if (e->use_coop)
         hipLaunchKernelGGL(parcdyn::k_dynamics_coop, dim3((e->N + CO_ENVS - 1) / CO_ENVS), dim3(64), 0, st, (const parcdyn::DynModel *)e->d_dyn,
                            (const parcdyn::CoopTables *)e->d_coop, T, e->sp.buf, action_dev, (const float *)e->d_env_off, e->N);
     else
