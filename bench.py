@@ -168,7 +168,13 @@ def main():
         post_traffic = (2.0 * pmc["FETCH_SIZE_KiB_avg_per_dispatch"][k] + pmc["WRITE_SIZE_KiB_avg_per_dispatch"][k]) * 1024.0
     post_gbs = BYTES_KINEMATIC * a.envs / (post_ms * 1e-3) / 1e9
     if dynamics_on:   # dominant kernel = k_dynamics: state 276 + action 112 in, state 276 + contact forces 180 out
-        kname, kms, bytes_per, traffic = "k_dynamics", dyn_ms, BYTES_DYN_KERNEL, None
+        kname = env._lib.parc_env_dynamics_kernel(env._handle).decode()
+        kms, bytes_per, traffic = dyn_ms, BYTES_DYN_KERNEL, None
+        dpmc = os.path.join(REPO, "profiles", "r01_pmc_dynamics.json")
+        if os.path.exists(dpmc) and a.envs == 65536:
+            dj = json.load(open(dpmc))
+            if dj.get("kernel") == kname:
+                traffic = 2.0 * dj["FETCH_SIZE_KiB"] * 1024.0 + dj["WRITE_SIZE_KiB"] * 1024.0
     else:
         kname, kms, bytes_per, traffic = "k_env_prep + k_env_post<MODE_STEP>", post_ms, BYTES_KINEMATIC, post_traffic
     achieved = bytes_per * a.envs / (kms * 1e-3) / 1e9
@@ -181,7 +187,9 @@ def main():
                    "envs_per_gpu": a.envs, "total_envs": a.envs * world, "dynamics": dynamics_on, "parallelism": f"env-shard x{world}"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "kernel": kname, "kernel_ms": kms, "algorithmic_bytes_per_env_step": bytes_per,
-                     "note": "k_dynamics is latency/scratch bound by construction (SURVEY 8d), far below the HBM ceiling",
+                     "note": ("the dynamics kernel is VALU-issue / latency bound (rigid-body recursion, ~47k VALU instructions per wave at 1 wave per SIMD; "
+                              "profiles/r01_pmc_dynamics.json), far below the HBM ceiling by construction (SURVEY 8d); obs_kernel is the HBM-bound one")
+                             if dynamics_on else "",
                      "obs_kernel": {"kernel": "k_env_prep + k_env_post<MODE_STEP>", "kernel_ms": post_ms, "achieved": post_gbs,
                                     "frac": post_gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_env_step": BYTES_KINEMATIC,
                                     "traffic": post_traffic},

@@ -228,6 +228,10 @@ int parc_env_profile_step(ParcEnv *env, const float *action_dev, void *stream, i
 /* average duration of k_dynamics in the last parc_env_profile_step call (0 when dynamics is off) */
 float parc_env_last_dynamics_ms(ParcEnv *env);
 
+/* name of the dynamics kernel this handle launches ("k_dynamics_wave", "k_dynamics_coop", "k_dynamics"; "" when
+ * dynamics is off).  The choice follows the shape of the kinematic tree (see parc_env_create). */
+const char *parc_env_dynamics_kernel(ParcEnv *env);
+
 #ifdef __cplusplus
 }
 #endif

@@ -169,6 +169,9 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
         if (brad < X.cell_min && bx >= 2 && bx < DYN_PATCH - 2 && by >= 2 && by < DYN_PATCH - 2 &&
             r.z + rootp.z + X.eo2 - brad > X.s_pmax[((bx - 2) * WV_PI + by - 2) * 64]) near = false;
     }
+#ifdef PARC_NO_CONTACT
+    near = false; // timing experiment only
+#endif
     if (near) {
         const int npt = W.npt[b], pt0 = W.pt0[b];
         for (int pi = 0; pi < npt; ++pi) {
@@ -180,13 +183,20 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
             const int pa_ = ix - X.pox, pb_ = iy - X.poy;
             const bool inp = pa_ >= 1 && pa_ < DYN_PATCH - 1 && pb_ >= 1 && pb_ < DYN_PATCH - 1;
             const float top0 = inp ? X.s_patch[(pa_ * DYN_PATCH + pb_) * 64] : hf_at(T, ix, iy);
-            const v3 vpt = s6lin(B.vel) + cross(s6ang(B.vel), x);
+            // candidate columns of this sphere: its own cell, and neighbours that stand higher (walls / edges); one bit each
+            unsigned cand = 0u;
+            PARC_UNROLL
             for (int nb = 0; nb < 9; ++nb) {
                 const int ox_ = (nb % 3) - 1, oy_ = (nb / 3) - 1;
-                const bool own = nb == 4;
-                const float top = own ? top0 : (inp ? X.s_patch[((pa_ + ox_) * DYN_PATCH + pb_ + oy_) * 64] : hf_at(T, ix + ox_, iy + oy_));
-                if (!own && !(top > top0 + 1e-3f)) continue;
-                if (g.z - rad > top) continue;
+                const float top = nb == 4 ? top0 : (inp ? X.s_patch[((pa_ + ox_) * DYN_PATCH + pb_ + oy_) * 64] : hf_at(T, ix + ox_, iy + oy_));
+                if ((nb == 4 || top > top0 + 1e-3f) && !(g.z - rad > top)) cand |= 1u << nb;
+            }
+            if (cand == 0u) continue;
+            const v3 vpt = s6lin(B.vel) + cross(s6ang(B.vel), x);
+            for (int nb = 0; nb < 9; ++nb) {
+                if (!((cand >> nb) & 1u)) continue;
+                const int ox_ = (nb % 3) - 1, oy_ = (nb / 3) - 1;
+                const float top = nb == 4 ? top0 : (inp ? X.s_patch[((pa_ + ox_) * DYN_PATCH + pb_ + oy_) * 64] : hf_at(T, ix + ox_, iy + oy_));
                 v3 n;
                 const float pen = sphere_vs_column(T, g, rad, ix + ox_, iy + oy_, top, n);
                 if (!(pen > 0.f)) continue;

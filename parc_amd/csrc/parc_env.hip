@@ -783,10 +783,24 @@ __global__ __launch_bounds__(256) void k_fail_rate_ema(const int *__restrict__ d
         const bool last = tile + 256 >= k;
         if (nmatch + 256 > EMA_CAP_BITS || (last && nmatch > 0)) { // flush: sequential chain over the buffered flags
             if (tid == 0) {
+                // the chain is inherently serial (each update rounds): keep only the two dependent VALU ops per entry on
+                // it -- flag words are fetched 4 at a time, addends are formed off the chain
                 float f = s_f;
-                for (int j = 0; j < nmatch; ++j) {
-                    const float add = ((s_bits[j >> 5] >> (j & 31)) & 1u) ? w : 0.0f;
-                    f = f * keep + add;
+                const int nw = (nmatch + 31) >> 5;
+                for (int wi = 0; wi < nw; wi += 4) {
+                    unsigned bw[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) bw[q] = wi + q < nw ? s_bits[wi + q] : 0u;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int cnt = min(32, nmatch - ((wi + q) << 5));
+                        if (cnt == 32) {
+#pragma unroll
+                            for (int j = 0; j < 32; ++j) { f = f * keep; f = f + (((bw[q] >> j) & 1u) ? w : 0.0f); }
+                        } else {
+                            for (int j = 0; j < cnt; ++j) { f = f * keep; f = f + (((bw[q] >> j) & 1u) ? w : 0.0f); }
+                        }
+                    }
                 }
                 s_f = f;
             }
@@ -1608,6 +1622,11 @@ extern "C" int parc_env_get_frame_vel_tables(ParcEnv *e, float *root_vel, float 
 }
 
 extern "C" float parc_env_last_dynamics_ms(ParcEnv *e) { return e ? e->last_dyn_ms : 0.f; }
+
+extern "C" const char *parc_env_dynamics_kernel(ParcEnv *e) {
+    if (!e || !e->cfg.enable_dynamics) return "";
+    return e->use_wave ? "k_dynamics_wave" : (e->use_coop ? "k_dynamics_coop" : "k_dynamics");
+}
 
 // Diagnostic (-DPARC_STAMPS builds): mean cycles per phase of k_env_post over all envs of the last step.
 extern "C" int parc_env_debug_stamps(ParcEnv *e, double *mean8) {
