@@ -10,11 +10,12 @@
 //   * a chain's joint state and kinematics stay in registers (k loops are fully unrolled, bodies are constants),
 //     the joint-space factors K = U D^-1 and D^-1 u park in LDS between the inward and the outward pass, laid out
 //     [slot][lane] so that every LDS access is conflict-free;
-//   * waves meet at three barriers per substep (trunk kinematics -> limbs in -> trunk in/out -> limbs out).
-// BUILD NOTE: the library is compiled with -fno-slp-vectorize.  With SLP vectorisation on, hipcc (ROCm 7.2) turns the
-// 3x3 / 6x6 algebra on wave-uniform model constants into v_pk_fma_f32 with op_sel on SGPR pairs and this kernel
-// computes wrong inertias on gfx950 (checked against the other two kernels and the CPU build; the scalar build agrees
-// with them to 1e-6).
+//   * waves meet at four barriers per substep (trunk kinematics | arms + feet in | upper trunk + legs in | root + trunk out | limbs out).
+// BUILD NOTE: the library is compiled with -fno-slp-vectorize.  With SLP vectorisation on, hipcc (ROCm 7.2) produces a
+// k_dynamics_wave whose 6x6 inertias are wrong on gfx950 (entries from index 2 on; found by comparing the three dynamics
+// kernels and the CPU build, tools/dyn_cmp.py); the scalar build agrees with them to 1e-6.  The cause was not isolated:
+// packed-fp32 operand selection on SGPR pairs was checked in isolation and behaves correctly, so the suspect is the
+// handling of 64-bit register pairs at this kernel's register pressure (256 VGPR + 242 AGPR).
 #pragma once
 #include "parc_dynamics_coop.hpp"
 
@@ -35,6 +36,7 @@ struct WaveTables {
     int len[1 + WV_MAXLIMB];               // chain 0 = trunk, 1.. = limbs
     int body[1 + WV_MAXLIMB][WV_MAXLEN];
     int par_slot[1 + WV_MAXLIMB];          // attach slot of the trunk body a limb hangs off
+    int early[1 + WV_MAXLIMB];             // limb hangs off a non-root trunk body: finished before the trunk's upper part starts
     int att_slot[WV_MAXLEN];               // per trunk position: attach slot or -1
     int nchild[WV_MAXLEN];                 // per trunk position: limbs hanging off it
     int child[WV_MAXLEN][WV_MAXLIMB];      // limb chain ids (1..)
@@ -69,6 +71,7 @@ inline bool build_wave_tables(const DynModel &M, const CoopTables &C, WaveTables
         if (pos < 0) return false; // limb does not hang off the trunk
         if (W.att_slot[pos] < 0) { if (natt >= WV_MAXATT) return false; W.att_slot[pos] = natt++; }
         W.par_slot[c] = W.att_slot[pos];
+        W.early[c] = pos > 0;
         W.child[pos][W.nchild[pos]++] = c;
     }
     for (int b = 0; b < M.B; ++b) { W.npt[b] = C.npt[b]; W.pt0[b] = C.pt0[b]; W.brad[b] = C.brad[b]; }
@@ -448,8 +451,29 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
         }
         __syncthreads();
         const v3 rootp = mk(s_rootp[0], s_rootp[64], s_rootp[128]);
-        // ---- phase 2: limb kinematics + inward pass (all waves) ---------------------------------------------------------
-        if (has_limb) {
+        // ---- phase 2: inward pass.  Limbs that hang off the upper trunk ("early": the arms) run completely in part A;
+        // limbs that hang off the root body ("late": the legs) do their tip body there (the foot, usually the one with
+        // contacts).  In part B wave 0 eliminates the non-root trunk bodies (head, torso: they need only the early limbs)
+        // while the late limbs finish; the root body follows after the next barrier.
+        sym6 Icl; s6 pcl = s6zero();   // carry of this wave's limb
+        PARC_UNROLL
+        for (int i = 0; i < 21; ++i) Icl.s[i] = 0.f;
+        const bool early = has_limb && W.early[lc] != 0;
+        auto limb_body = [&](int k) __attribute__((always_inline)) {
+            const int b = W.body[lc][k];
+            const m3 R = qmat(limb[k].bq);
+            sym6 IA = Icl; s6 pA = pcl;
+            wv_body_inertia(M, W, T, X, b, limb[k], R, rootp, IA, pA);
+            wv_joint_inward(M, b, limb[k], R, dt, IA, pA, Icl, pcl, s_fac + (lc * WV_MAXLEN + k) * WV_FAC * 64);
+        };
+        auto limb_handover = [&]() __attribute__((always_inline)) {
+            float *u = s_up + (lc - 1) * 27 * 64;
+            PARC_UNROLL
+            for (int i = 0; i < 21; ++i) u[i * 64] = Icl.s[i];
+            PARC_UNROLL
+            for (int a = 0; a < 6; ++a) u[(21 + a) * 64] = pcl.a[a];
+        };
+        if (has_limb) { // part A
             const float *s = s_attkin + W.par_slot[lc] * 13 * 64;
             q4 pq; pq.x = s[0]; pq.y = s[64]; pq.z = s[128]; pq.w = s[192];
             v3 pr = mk(s[256], s[320], s[384]);
@@ -458,90 +482,81 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
             for (int a = 0; a < 6; ++a) pv.a[a] = s[(7 + a) * 64];
             PARC_UNROLL
             for (int k = 0; k < WV_MAXLEN; ++k) if (k < llen) wv_fk_body(M, W.body[lc][k], limb[k], pq, pr, pv);
-            sym6 Ic; s6 pc = s6zero();
             PARC_UNROLL
-            for (int i = 0; i < 21; ++i) Ic.s[i] = 0.f;
-            PARC_UNROLL
-            for (int kk = 0; kk < WV_MAXLEN; ++kk) {
-                const int k = WV_MAXLEN - 1 - kk;
-                if (k < llen) {
-                    const int b = W.body[lc][k];
-                    const m3 R = qmat(limb[k].bq);
-                    sym6 IA = Ic; s6 pA = pc;
-                    wv_body_inertia(M, W, T, X, b, limb[k], R, rootp, IA, pA);
-                    wv_joint_inward(M, b, limb[k], R, dt, IA, pA, Ic, pc, s_fac + (lc * WV_MAXLEN + k) * WV_FAC * 64);
-                }
-            }
-            float *u = s_up + (lc - 1) * 27 * 64;
-            PARC_UNROLL
-            for (int i = 0; i < 21; ++i) u[i * 64] = Ic.s[i];
-            PARC_UNROLL
-            for (int a = 0; a < 6; ++a) u[(21 + a) * 64] = pc.a[a];
+            for (int k = WV_MAXLEN - 1; k >= 0; --k)
+                if (k < llen && (early || k == llen - 1)) limb_body(k);
+            if (early || llen == 1) limb_handover();
         }
         __syncthreads();
-        // ---- phase 3: trunk inward, floating-base solve, trunk outward, trunk/root integration (wave 0) --------------
-        if (w == 0) {
-            sym6 Ic; s6 pc = s6zero();
-            PARC_UNROLL
-            for (int i = 0; i < 21; ++i) Ic.s[i] = 0.f;
-            s6 acc_root = s6zero();
-            PARC_UNROLL
-            for (int kk = 0; kk < WV_MAXLEN; ++kk) {
-                const int k = WV_MAXLEN - 1 - kk;
-                if (k < tlen) {
-                    const int b = W.body[0][k];
-                    const m3 R = qmat(trunk[k].bq);
-                    sym6 IA = Ic; s6 pA = pc;
-                    wv_body_inertia(M, W, T, X, b, trunk[k], R, rootp, IA, pA);
-                    for (int ci = 0; ci < W.nchild[k]; ++ci) {
-                        const float *u = s_up + (W.child[k][ci] - 1) * 27 * 64;
-                        PARC_UNROLL
-                        for (int i = 0; i < 21; ++i) IA.s[i] += u[i * 64];
-                        PARC_UNROLL
-                        for (int a = 0; a < 6; ++a) pA.a[a] += u[(21 + a) * 64];
-                    }
-                    if (b == 0) { // floating base: solve IA a0 = -pA (Cholesky)
-                        float Lm[6][6];
-                        PARC_UNROLL
-                        for (int j = 0; j < 6; ++j) {
-                            float sd = sget(IA, j, j);
-                            PARC_UNROLL
-                            for (int q = 0; q < j; ++q) sd -= Lm[j][q] * Lm[j][q];
-                            sd = sd > 1e-12f ? sqrtf(sd) : 1e-6f;
-                            Lm[j][j] = sd;
-                            const float isd = 1.f / sd;
-                            PARC_UNROLL
-                            for (int a = j + 1; a < 6; ++a) {
-                                float sa = sget(IA, a, j);
-                                PARC_UNROLL
-                                for (int q = 0; q < j; ++q) sa -= Lm[a][q] * Lm[j][q];
-                                Lm[a][j] = sa * isd;
-                            }
-                            Lm[j][j] = isd; // keep the reciprocal of the pivot
-                        }
-                        float y[6], xs[6];
-                        PARC_UNROLL
-                        for (int a = 0; a < 6; ++a) {
-                            float sa = -pA.a[a];
-                            PARC_UNROLL
-                            for (int q = 0; q < a; ++q) sa -= Lm[a][q] * y[q];
-                            y[a] = sa * Lm[a][a];
-                        }
-                        PARC_UNROLL
-                        for (int a_ = 0; a_ < 6; ++a_) {
-                            const int a = 5 - a_;
-                            float sa = y[a];
-                            PARC_UNROLL
-                            for (int q = a + 1; q < 6; ++q) sa -= Lm[q][a] * xs[q];
-                            xs[a] = sa * Lm[a][a];
-                        }
-                        PARC_UNROLL
-                        for (int a = 0; a < 6; ++a) acc_root.a[a] = xs[a];
-                    } else {
-                        wv_joint_inward(M, b, trunk[k], R, dt, IA, pA, Ic, pc, s_fac + k * WV_FAC * 64);
-                    }
-                }
+        sym6 Ict; s6 pct = s6zero();   // carry of the trunk
+        PARC_UNROLL
+        for (int i = 0; i < 21; ++i) Ict.s[i] = 0.f;
+        s6 acc_root = s6zero();
+        auto trunk_body = [&](int k) __attribute__((always_inline)) {
+            const int b = W.body[0][k];
+            const m3 R = qmat(trunk[k].bq);
+            sym6 IA = Ict; s6 pA = pct;
+            wv_body_inertia(M, W, T, X, b, trunk[k], R, rootp, IA, pA);
+            for (int ci = 0; ci < W.nchild[k]; ++ci) {
+                const float *u = s_up + (W.child[k][ci] - 1) * 27 * 64;
+                PARC_UNROLL
+                for (int i = 0; i < 21; ++i) IA.s[i] += u[i * 64];
+                PARC_UNROLL
+                for (int a = 0; a < 6; ++a) pA.a[a] += u[(21 + a) * 64];
             }
+            if (b == 0) { // floating base: solve IA a0 = -pA (Cholesky)
+                float Lm[6][6];
+                PARC_UNROLL
+                for (int j = 0; j < 6; ++j) {
+                    float sd = sget(IA, j, j);
+                    PARC_UNROLL
+                    for (int q = 0; q < j; ++q) sd -= Lm[j][q] * Lm[j][q];
+                    sd = sd > 1e-12f ? sqrtf(sd) : 1e-6f;
+                    const float isd = 1.f / sd;
+                    PARC_UNROLL
+                    for (int a = j + 1; a < 6; ++a) {
+                        float sa = sget(IA, a, j);
+                        PARC_UNROLL
+                        for (int q = 0; q < j; ++q) sa -= Lm[a][q] * Lm[j][q];
+                        Lm[a][j] = sa * isd;
+                    }
+                    Lm[j][j] = isd; // the reciprocal of the pivot
+                }
+                float y[6], xs[6];
+                PARC_UNROLL
+                for (int a = 0; a < 6; ++a) {
+                    float sa = -pA.a[a];
+                    PARC_UNROLL
+                    for (int q = 0; q < a; ++q) sa -= Lm[a][q] * y[q];
+                    y[a] = sa * Lm[a][a];
+                }
+                PARC_UNROLL
+                for (int a_ = 0; a_ < 6; ++a_) {
+                    const int a = 5 - a_;
+                    float sa = y[a];
+                    PARC_UNROLL
+                    for (int q = a + 1; q < 6; ++q) sa -= Lm[q][a] * xs[q];
+                    xs[a] = sa * Lm[a][a];
+                }
+                PARC_UNROLL
+                for (int a = 0; a < 6; ++a) acc_root.a[a] = xs[a];
+            } else {
+                wv_joint_inward(M, b, trunk[k], R, dt, IA, pA, Ict, pct, s_fac + k * WV_FAC * 64);
+            }
+        };
+        if (w == 0) { // part B, trunk: every body but the root
+            PARC_UNROLL
+            for (int k = WV_MAXLEN - 1; k >= 1; --k) if (k < tlen) trunk_body(k);
+        }
+        if (has_limb && !early && llen > 1) { // part B, late limbs: the rest of the chain
+            PARC_UNROLL
+            for (int k = WV_MAXLEN - 2; k >= 0; --k) if (k < llen - 1) limb_body(k);
+            limb_handover();
+        }
+        __syncthreads();
+        // ---- phase 3: root body, floating-base solve, trunk outward, trunk/root integration (wave 0) ------------------
+        if (w == 0) {
+            trunk_body(0);
             s6 ap = acc_root;
             PARC_UNROLL
             for (int k = 0; k < WV_MAXLEN; ++k) {
