@@ -405,3 +405,42 @@ def test_ppo_training_iterations_on_hip_env(tmp_path):
     agent.save(str(tmp_path / "model.pt"))
     sd = torch.load(str(tmp_path / "model.pt"), weights_only=True)
     assert "_model._actor_layers.0.weight" in sd and "_obs_norm._mean" in sd
+
+
+def test_dynamics_kernels_agree(tmp_path, monkeypatch):
+    """The three dynamics kernels (wave-per-limb, chain-parallel, thread-per-env) integrate the same equations: one control
+    step from the same state must agree to rounding.  Guards against miscompiles of the register-heavy wave kernel."""
+    import torch
+    from gpu_helpers import default_config, write_motion_yaml, to_np
+    from parc_amd.envs.hip_parkour_env import HipParkourEnv
+    n = 512
+    envs = {}
+    for kern in ("wave", "coop", "thread"):
+        monkeypatch.setenv("PARC_DYN_KERNEL", kern)
+        cfg = default_config()
+        cfg["env"]["dm"]["motion_file"] = write_motion_yaml(tmp_path, ["civilization", "sfu"], [1.0, 1.0])
+        env = HipParkourEnv(cfg, n, "cuda:0", False, seed=9, enable_dynamics=True, mirror_ref_state=True)
+        env.reset()
+        envs[kern] = env
+    names = {"wave": "k_dynamics_wave", "coop": "k_dynamics_coop", "thread": "k_dynamics"}
+    for kern, env in envs.items():
+        assert env._lib.parc_env_dynamics_kernel(env._handle).decode() == names[kern]
+    state = ["_char_root_pos", "_char_root_rot", "_char_root_vel", "_char_root_ang_vel", "_char_dof_pos", "_char_dof_vel"]
+    tol = {"_char_root_pos": 1e-4, "_char_root_rot": 1e-4, "_char_root_vel": 2e-3, "_char_root_ang_vel": 1e-2, "_char_dof_pos": 2e-4,
+           "_char_dof_vel": 5e-2}
+    ref = envs["wave"]
+    g = torch.Generator(device="cuda:0"); g.manual_seed(3)
+    for it in range(4):
+        act = (ref._char_dof_pos + 0.1 * torch.randn(ref._char_dof_pos.shape, device="cuda:0", generator=g)).contiguous()
+        for kern in ("coop", "thread"):
+            for nm in state + ["_char_contact_forces"]:
+                getattr(envs[kern], nm).copy_(getattr(ref, nm))
+        for env in envs.values():
+            env.step(act)
+        for kern in ("coop", "thread"):
+            for nm in state:
+                a, b = to_np(getattr(ref, nm)), to_np(getattr(envs[kern], nm))
+                assert np.isfinite(a).all() and np.isfinite(b).all(), (it, kern, nm)
+                assert np.abs(a - b).max() <= tol[nm], (it, kern, nm, np.abs(a - b).max())
+            fa, fb = to_np(ref._char_contact_forces), to_np(envs[kern]._char_contact_forces)
+            assert np.abs(fa - fb).max() <= 1.0 + 1e-3 * np.abs(fa).max(), (it, kern, np.abs(fa - fb).max())
