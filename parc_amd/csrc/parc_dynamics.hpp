@@ -33,6 +33,22 @@
 #define PARC_UNROLL
 #endif
 
+// Device-side reciprocal / square root / sin / cos of the dynamics use the hardware approximations (v_rcp_f32, v_sqrt_f32,
+// v_sin_f32: ~1 ulp, resp. ~1e-6 absolute for the half-angles that occur here) instead of the correctly rounded OCML
+// sequences: nothing here has a bit-exact reference and the integrator's own truncation error is orders larger.  The
+// host build (tests) uses libm.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DYN_RCP(x) __builtin_amdgcn_rcpf(x)
+#define DYN_SQRT(x) __builtin_amdgcn_sqrtf(x)
+#define DYN_SIN(x) __sinf(x)
+#define DYN_COS(x) __cosf(x)
+#else
+#define DYN_RCP(x) (1.f / (x))
+#define DYN_SQRT(x) sqrtf(x)
+#define DYN_SIN(x) sinf(x)
+#define DYN_COS(x) cosf(x)
+#endif
+
 // The dynamics has no bit-exact reference (parity with PhysX is unpinned, the CPU build is compared by tolerance), so the
 // device build may fuse multiply-adds here even though the rest of the library is built with -ffp-contract=off.
 #if defined(__HIPCC__)
@@ -96,27 +112,27 @@ PARC_HD q4 qmul(q4 a, q4 b) {
 }
 PARC_HD q4 qconj(q4 a) { q4 r; r.x = -a.x; r.y = -a.y; r.z = -a.z; r.w = a.w; return r; }
 PARC_HD q4 qnormalize(q4 a) {
-    float n = sqrtf(a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w);
-    n = n > 1e-12f ? 1.f / n : 0.f;
+    float n = DYN_SQRT(a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w);
+    n = n > 1e-12f ? DYN_RCP(n) : 0.f;
     q4 r; r.x = a.x * n; r.y = a.y * n; r.z = a.z * n; r.w = a.w * n;
     if (n == 0.f) r.w = 1.f;
     return r;
 }
 // rotation-vector -> quaternion
 PARC_HD q4 qexp(v3 v) {
-    float a = sqrtf(dot(v, v));
+    float a = DYN_SQRT(dot(v, v));
     q4 r;
     if (a < 1e-6f) { r.x = 0.5f * v.x; r.y = 0.5f * v.y; r.z = 0.5f * v.z; r.w = 1.f; return qnormalize(r); }
-    float s = sinf(0.5f * a) / a;
-    r.x = s * v.x; r.y = s * v.y; r.z = s * v.z; r.w = cosf(0.5f * a);
+    float s = DYN_SIN(0.5f * a) * DYN_RCP(a);
+    r.x = s * v.x; r.y = s * v.y; r.z = s * v.z; r.w = DYN_COS(0.5f * a);
     return r;
 }
 // quaternion -> rotation vector with angle in [0, pi] (the reference's quat_to_exp_map convention)
 PARC_HD v3 qlog(q4 q) {
     if (q.w < 0.f) { q.x = -q.x; q.y = -q.y; q.z = -q.z; q.w = -q.w; }
-    float l = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z);
+    float l = DYN_SQRT(q.x * q.x + q.y * q.y + q.z * q.z);
     if (l < 1e-6f) return mk(2.f * q.x, 2.f * q.y, 2.f * q.z);
-    float a = 2.f * atan2f(l, q.w) / l;
+    float a = 2.f * atan2f(l, q.w) * DYN_RCP(l);
     return mk(a * q.x, a * q.y, a * q.z);
 }
 struct m3 { float m[3][3]; };
@@ -200,7 +216,7 @@ struct Patch {
     int ox, oy; // global cell index of patch (0,0)
 };
 PARC_HD int cell_of(float p, float mn, float d) { // terrain_util.py:146-152 nearest cell, unclamped
-    float f = rintf((p - mn) / d);
+    float f = rintf((p - mn) * DYN_RCP(d));
     f = f < -1.0e9f ? -1.0e9f : (f > 1.0e9f ? 1.0e9f : f);
     return (int)f;
 }
@@ -231,8 +247,8 @@ PARC_HD float sphere_vs_column(const DynTerrain &T, v3 s, float r, int ix, int i
     v3 d = mk(s.x - qx, s.y - qy, s.z - qz);
     float dist2 = dot(d, d);
     if (dist2 > 1e-12f) {
-        float dist = sqrtf(dist2);
-        n = (1.f / dist) * d;
+        float dist = DYN_SQRT(dist2);
+        n = DYN_RCP(dist) * d;
         return r - dist;
     }
     // centre inside the column: leave through the top (lateral escapes are handled by the neighbour test order)

@@ -207,9 +207,9 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
                 float fn = M.kn * pen - M.dn * vn;
                 if (fn < 0.f) fn = 0.f;
                 const v3 vt = vpt - vn * n;
-                const float vtm = sqrtf(dot(vt, vt));
+                const float vtm = DYN_SQRT(dot(vt, vt));
                 float beta = M.dtang;
-                if (beta * vtm > M.mu * fn) beta = vtm > 1e-9f ? M.mu * fn / vtm : 0.f;
+                if (beta * vtm > M.mu * fn) beta = vtm > 1e-9f ? M.mu * fn * DYN_RCP(vtm) : 0.f;
                 const v3 f = fn * n - beta * vt;
                 const v3 no = cross(x, f);
                 pA.a[0] -= no.x; pA.a[1] -= no.y; pA.a[2] -= no.z; pA.a[3] -= f.x; pA.a[4] -= f.y; pA.a[5] -= f.z;
@@ -266,7 +266,7 @@ __device__ __forceinline__ void wv_joint_inward(const DynModel &M, int b, const 
         }
         const float c00 = Dm[1][1] * Dm[2][2] - Dm[1][2] * Dm[2][1], c01 = Dm[0][2] * Dm[2][1] - Dm[0][1] * Dm[2][2],
                     c02 = Dm[0][1] * Dm[1][2] - Dm[0][2] * Dm[1][1];
-        const float id = 1.f / (Dm[0][0] * c00 + Dm[1][0] * c01 + Dm[2][0] * c02);
+        const float id = DYN_RCP(Dm[0][0] * c00 + Dm[1][0] * c01 + Dm[2][0] * c02);
         float D3[3][3];
         D3[0][0] = c00 * id; D3[0][1] = c01 * id; D3[0][2] = c02 * id;
         D3[1][1] = (Dm[0][0] * Dm[2][2] - Dm[0][2] * Dm[2][0]) * id;
@@ -308,7 +308,7 @@ __device__ __forceinline__ void wv_joint_inward(const DynModel &M, int b, const 
         float sp = 0.f, d = aug;
         PARC_UNROLL
         for (int q = 0; q < 6; ++q) { sp += Sc.a[q] * pA.a[q]; d += Sc.a[q] * Uc.a[q]; }
-        const float uu = t - sp, di_ = 1.f / d;
+        const float uu = t - sp, di_ = DYN_RCP(d);
         s6 Kc;
         PARC_UNROLL
         for (int q = 0; q < 6; ++q) Kc.a[q] = Uc.a[q] * di_;
@@ -511,8 +511,8 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
                     float sd = sget(IA, j, j);
                     PARC_UNROLL
                     for (int q = 0; q < j; ++q) sd -= Lm[j][q] * Lm[j][q];
-                    sd = sd > 1e-12f ? sqrtf(sd) : 1e-6f;
-                    const float isd = 1.f / sd;
+                    sd = sd > 1e-12f ? DYN_SQRT(sd) : 1e-6f;
+                    const float isd = DYN_RCP(sd);
                     PARC_UNROLL
                     for (int a = j + 1; a < 6; ++a) {
                         float sa = sget(IA, a, j);
@@ -575,9 +575,9 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
                 const v3 alpha = s6ang(acc_root), aO = s6lin(acc_root);
                 const v3 rv_new = rv + dt * (aO + cross(rw, rv));
                 v3 rw_new = rw + dt * alpha;
-                rw_new = (1.f / (1.f + dt * M.ang_damping)) * rw_new;
-                const float wm = sqrtf(dot(rw_new, rw_new));
-                if (wm > M.max_ang_vel) rw_new = (M.max_ang_vel / wm) * rw_new;
+                rw_new = DYN_RCP(1.f + dt * M.ang_damping) * rw_new;
+                const float wm = DYN_SQRT(dot(rw_new, rw_new));
+                if (wm > M.max_ang_vel) rw_new = (M.max_ang_vel * DYN_RCP(wm)) * rw_new;
                 rv = rv_new; rw = rw_new;
                 rp = rp + dt * rv;
                 rq = qnormalize(qmul(qexp(dt * rw), rq));
