@@ -37,6 +37,7 @@ struct WaveTables {
     int body[1 + WV_MAXLIMB][WV_MAXLEN];
     int par_slot[1 + WV_MAXLIMB];          // attach slot of the trunk body a limb hangs off
     int early[1 + WV_MAXLIMB];             // limb hangs off a non-root trunk body: finished before the trunk's upper part starts
+    int helper;                            // wave (>= 1) of an early limb: idle in part B, it prepares the root body's own inertia + contacts; -1 if none
     int att_slot[WV_MAXLEN];               // per trunk position: attach slot or -1
     int nchild[WV_MAXLEN];                 // per trunk position: limbs hanging off it
     int child[WV_MAXLEN][WV_MAXLIMB];      // limb chain ids (1..)
@@ -52,7 +53,8 @@ struct WaveTables {
 #define WV_OFF_PATCH (WV_OFF_ROOTP + 3 * 64)
 #define WV_OFF_PMAX (WV_OFF_PATCH + DYN_PATCH * DYN_PATCH * 64)
 #define WV_OFF_FAC (WV_OFF_PMAX + WV_PI * WV_PI * 64)
-#define WV_LDS_FLOATS (WV_OFF_FAC + (1 + WV_MAXLIMB) * WV_MAXLEN * WV_FAC * 64)
+#define WV_OFF_ROOTI (WV_OFF_FAC + (1 + WV_MAXLIMB) * WV_MAXLEN * WV_FAC * 64)
+#define WV_LDS_FLOATS (WV_OFF_ROOTI + 30 * 64)
 
 inline bool build_wave_tables(const DynModel &M, const CoopTables &C, WaveTables &W) {
     memset(&W, 0, sizeof(W));
@@ -75,6 +77,8 @@ inline bool build_wave_tables(const DynModel &M, const CoopTables &C, WaveTables
         W.child[pos][W.nchild[pos]++] = c;
     }
     for (int b = 0; b < M.B; ++b) { W.npt[b] = C.npt[b]; W.pt0[b] = C.pt0[b]; W.brad[b] = C.brad[b]; }
+    W.helper = -1;
+    for (int c = 2; c < C.nchain; ++c) if (W.early[c] && W.att_slot[0] >= 0) { W.helper = c - 1; break; }
     return true;
 }
 
@@ -399,7 +403,7 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
 
     float *s_attkin = smem + WV_OFF_ATTKIN + lane, *s_up = smem + WV_OFF_UP + lane, *s_attacc = smem + WV_OFF_ATTACC + lane;
     float *s_rootp = smem + WV_OFF_ROOTP + lane, *s_patch = smem + WV_OFF_PATCH + lane, *s_pmax = smem + WV_OFF_PMAX + lane;
-    float *s_fac = smem + WV_OFF_FAC + lane;
+    float *s_fac = smem + WV_OFF_FAC + lane, *s_rooti = smem + WV_OFF_ROOTI + lane;
 
     const float *dp = buf.char_dof_pos + (size_t)D_ * ec, *dv = buf.char_dof_vel + (size_t)D_ * ec, *ac = action + (size_t)D_ * ec;
     WvBody limb[WV_MAXLEN], trunk[WV_MAXLEN];
@@ -496,7 +500,15 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
             const int b = W.body[0][k];
             const m3 R = qmat(trunk[k].bq);
             sym6 IA = Ict; s6 pA = pct;
-            wv_body_inertia(M, W, T, X, b, trunk[k], R, rootp, IA, pA);
+            if (k == 0 && W.helper >= 0) { // prepared by the helper wave during part B
+                PARC_UNROLL
+                for (int i = 0; i < 21; ++i) IA.s[i] += s_rooti[i * 64];
+                PARC_UNROLL
+                for (int a = 0; a < 6; ++a) pA.a[a] += s_rooti[(21 + a) * 64];
+                trunk[k].fcon = mk(s_rooti[27 * 64], s_rooti[28 * 64], s_rooti[29 * 64]);
+            } else {
+                wv_body_inertia(M, W, T, X, b, trunk[k], R, rootp, IA, pA);
+            }
             for (int ci = 0; ci < W.nchild[k]; ++ci) {
                 const float *u = s_up + (W.child[k][ci] - 1) * 27 * 64;
                 PARC_UNROLL
@@ -547,6 +559,23 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
         if (w == 0) { // part B, trunk: every body but the root
             PARC_UNROLL
             for (int k = WV_MAXLEN - 1; k >= 1; --k) if (k < tlen) trunk_body(k);
+        }
+        if (w == W.helper) { // part B, helper: own inertia + contacts of the trunk's root body (its kinematics are in the attach slot)
+            const float *s = s_attkin + W.att_slot[0] * 13 * 64;
+            WvBody rb;
+            rb.bq.x = s[0]; rb.bq.y = s[64]; rb.bq.z = s[128]; rb.bq.w = s[192];
+            rb.r = mk(s[256], s[320], s[384]);
+            PARC_UNROLL
+            for (int a = 0; a < 6; ++a) rb.vel.a[a] = s[(7 + a) * 64];
+            sym6 IA; s6 pA = s6zero();
+            PARC_UNROLL
+            for (int i = 0; i < 21; ++i) IA.s[i] = 0.f;
+            wv_body_inertia(M, W, T, X, W.body[0][0], rb, qmat(rb.bq), rootp, IA, pA);
+            PARC_UNROLL
+            for (int i = 0; i < 21; ++i) s_rooti[i * 64] = IA.s[i];
+            PARC_UNROLL
+            for (int a = 0; a < 6; ++a) s_rooti[(21 + a) * 64] = pA.a[a];
+            s_rooti[27 * 64] = rb.fcon.x; s_rooti[28 * 64] = rb.fcon.y; s_rooti[29 * 64] = rb.fcon.z;
         }
         if (has_limb && !early && llen > 1) { // part B, late limbs: the rest of the chain
             PARC_UNROLL
