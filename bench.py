@@ -108,7 +108,9 @@ def cpu_baseline(env, seconds, dynamics_on, actions):
 
 def main():
     a = parse()
+    import ctypes as C
     import torch
+    from parc_amd import lib as L
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     # rehearsal switches for a one-GPU box (never set by the driver): all ranks on cuda:0, gloo for the barrier / max
@@ -149,6 +151,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    L.check(env._lib.parc_env_set_kernel_timing(env._handle, 1))  # hipEvents around the kernels of the timed steps, no sync
     t0 = time.perf_counter()
     for i in range(a.steps):
         one_step(i)
@@ -162,9 +165,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # dominant kernel, measured live with hipEvents on the launch stream
-    tot_ms, post_ms = env.profile_step(iters=20, action=actions[0])
-    dyn_ms = float(env._lib.parc_env_last_dynamics_ms(env._handle))
+    # kernel durations over the timed region: hipEvents recorded on the launch stream by every parc_env_step
+    dms, pms, nst = C.c_double(), C.c_double(), C.c_int32()
+    L.check(env._lib.parc_env_get_kernel_timing(env._handle, C.byref(dms), C.byref(pms), C.byref(nst)))
+    L.check(env._lib.parc_env_set_kernel_timing(env._handle, 0))
+    assert nst.value == a.steps
+    dyn_ms, post_ms = float(dms.value), float(pms.value)
     # HBM traffic of k_env_post from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs;
     # FETCH_SIZE doubled per the gfx950 correction).  Only valid for the configuration it was collected on.
     post_traffic = None

@@ -228,6 +228,14 @@ int parc_env_profile_step(ParcEnv *env, const float *action_dev, void *stream, i
 /* average duration of k_dynamics in the last parc_env_profile_step call (0 when dynamics is off) */
 float parc_env_last_dynamics_ms(ParcEnv *env);
 
+/* Kernel timing over a run of ordinary parc_env_step calls (what bench.py reports as the roofline's kernel duration).
+ * While enabled, every step records three events on the caller's stream (before the dynamics kernel, after it, after
+ * the observation kernels); nothing synchronises.  parc_env_get_kernel_timing waits for the last step, returns the
+ * average duration of the dynamics kernel and of k_env_prep + k_env_post<STEP> over the steps since the last call, and
+ * clears the record. */
+int parc_env_set_kernel_timing(ParcEnv *env, int32_t enable);
+int parc_env_get_kernel_timing(ParcEnv *env, double *dynamics_ms_avg, double *obs_ms_avg, int32_t *steps);
+
 /* name of the dynamics kernel this handle launches ("k_dynamics_wave", "k_dynamics_coop", "k_dynamics"; "" when
  * dynamics is off).  The choice follows the shape of the kinematic tree (see parc_env_create). */
 const char *parc_env_dynamics_kernel(ParcEnv *env);

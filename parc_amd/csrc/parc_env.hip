@@ -750,21 +750,21 @@ __global__ __launch_bounds__(1024) void k_done_scatter(const unsigned char *__re
 // f <- f*(1-w) + (FAIL ? w : 0)  (adding +0.0f leaves f*(1-w) unchanged, so this is the reference's two-branch
 // update, dm_env.py:651-658, bit for bit).
 #define EMA_CAP_BITS 65536
-__global__ __launch_bounds__(256) void k_fail_rate_ema(const int *__restrict__ done_key, const int *__restrict__ reset_count,
+__global__ __launch_bounds__(1024) void k_fail_rate_ema(const int *__restrict__ done_key, const int *__restrict__ reset_count,
                                                        float *fail_rates, int M, float w) {
     __shared__ unsigned s_bits[EMA_CAP_BITS / 32];
-    __shared__ int s_wtot[4];
+    __shared__ int s_wtot[16];
     __shared__ float s_f;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = blockIdx.x;
     const int k = *reset_count;
     if (k == 0 || m >= M) return;
     const float keep = (float)(1.0 - (double)w);
-    for (int i = tid; i < EMA_CAP_BITS / 32; i += 256) s_bits[i] = 0u;
+    for (int i = tid; i < EMA_CAP_BITS / 32; i += 1024) s_bits[i] = 0u;
     if (tid == 0) s_f = fail_rates[m];
     __syncthreads();
     int nmatch = 0;
     bool any = false;
-    for (int tile = 0; tile < k; tile += 256) {
+    for (int tile = 0; tile < k; tile += 1024) {
         const int i = tile + tid;
         const int v = i < k ? done_key[i] : -2;
         const bool match = (v >> 1) == m;
@@ -772,7 +772,7 @@ __global__ __launch_bounds__(256) void k_fail_rate_ema(const int *__restrict__ d
         if (lane == 0) s_wtot[wv] = __popcll(mask);
         __syncthreads();
         int woff = 0, total = 0;
-        for (int q = 0; q < 4; ++q) { const int c = s_wtot[q]; if (q < wv) woff += c; total += c; }
+        for (int q = 0; q < 16; ++q) { const int c = s_wtot[q]; if (q < wv) woff += c; total += c; }
         if (match && (v & 1)) {
             const int pos = nmatch + woff + __popcll(mask & ((1ull << lane) - 1ull));
             atomicOr(&s_bits[pos >> 5], 1u << (pos & 31));
@@ -780,8 +780,8 @@ __global__ __launch_bounds__(256) void k_fail_rate_ema(const int *__restrict__ d
         nmatch += total;
         any = any || total > 0;
         __syncthreads();
-        const bool last = tile + 256 >= k;
-        if (nmatch + 256 > EMA_CAP_BITS || (last && nmatch > 0)) { // flush: sequential chain over the buffered flags
+        const bool last = tile + 1024 >= k;
+        if (nmatch + 1024 > EMA_CAP_BITS || (last && nmatch > 0)) { // flush: sequential chain over the buffered flags
             if (tid == 0) {
                 // the chain is inherently serial (each update rounds): keep only the two dependent VALU ops per entry on
                 // it -- flag words are fetched 4 at a time, addends are formed off the chain
@@ -805,7 +805,7 @@ __global__ __launch_bounds__(256) void k_fail_rate_ema(const int *__restrict__ d
                 s_f = f;
             }
             __syncthreads();
-            if (!last) for (int q = tid; q < EMA_CAP_BITS / 32; q += 256) s_bits[q] = 0u;
+            if (!last) for (int q = tid; q < EMA_CAP_BITS / 32; q += 1024) s_bits[q] = 0u;
             nmatch = 0;
             __syncthreads();
         }
@@ -1118,6 +1118,9 @@ struct ParcEnv {
     size_t lds_bytes = 0;
     float last_dyn_ms = 0.f;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool timing = false;               // parc_env_set_kernel_timing: record events around the kernels of every step
+    std::vector<hipEvent_t> tev;       // 3 events per timed step (before dynamics, after dynamics, after the obs kernels)
+    size_t tev_used = 0;
 };
 
 extern "C" const char *parc_last_error(void) { return g_err.c_str(); }
@@ -1129,6 +1132,7 @@ static void free_dev(ParcEnv *e) {
                     e->d_scratch_jr};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &ev : e->ev) if (ev) (void)hipEventDestroy(ev);
+    for (auto &ev : e->tev) if (ev) (void)hipEventDestroy(ev);
 }
 
 static int sync_params(ParcEnv *e) { // the kernels read StepParams through a device pointer
@@ -1440,7 +1444,7 @@ static int launch_dynamics(ParcEnv *e, const float *action_dev, hipStream_t st) 
 static int launch_curriculum(ParcEnv *e, hipStream_t st) {
     hipLaunchKernelGGL(k_done_scatter, dim3(e->nchunks), dim3(1024), 0, st, e->d_ema, e->sp.buf.motion_ids, e->N, e->d_done_list,
                        e->d_done_key, e->d_reset_count);
-    hipLaunchKernelGGL(k_fail_rate_ema, dim3(e->M), dim3(256), 0, st, e->d_done_key, e->d_reset_count, e->d_fail, e->M,
+    hipLaunchKernelGGL(k_fail_rate_ema, dim3(e->M), dim3(1024), 0, st, e->d_done_key, e->d_reset_count, e->d_fail, e->M,
                        e->cfg.fail_rate_ema_weight);
     HIPCHK(hipGetLastError());
     return PARC_OK;
@@ -1461,11 +1465,49 @@ extern "C" int parc_env_step(ParcEnv *e, const float *action_dev, void *stream) 
     int rc = check_ready(e);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
+    hipEvent_t *tv = nullptr;
+    if (e->timing) { // no host synchronisation: events come from a growing pool and are read back by parc_env_get_kernel_timing
+        if (e->tev_used + 3 > e->tev.size()) {
+            const size_t old = e->tev.size();
+            e->tev.resize(old + 768, nullptr);
+            for (size_t i = old; i < e->tev.size(); ++i) HIPCHK(hipEventCreate(&e->tev[i]));
+        }
+        tv = &e->tev[e->tev_used];
+        e->tev_used += 3;
+        HIPCHK(hipEventRecord(tv[0], st));
+    }
     rc = launch_dynamics(e, action_dev, st);
     if (rc) return rc;
+    if (tv) HIPCHK(hipEventRecord(tv[1], st));
     rc = launch_post(e, MODE_STEP, nullptr, e->N, st);
     if (rc) return rc;
+    if (tv) HIPCHK(hipEventRecord(tv[2], st));
     return launch_curriculum(e, st);
+}
+
+extern "C" int parc_env_set_kernel_timing(ParcEnv *e, int32_t enable) {
+    if (!e) return fail(PARC_ERR_INVALID, "null env");
+    e->timing = enable != 0;
+    e->tev_used = 0;
+    return PARC_OK;
+}
+
+extern "C" int parc_env_get_kernel_timing(ParcEnv *e, double *dynamics_ms_avg, double *obs_ms_avg, int32_t *steps) {
+    if (!e) return fail(PARC_ERR_INVALID, "null env");
+    const size_t n = e->tev_used / 3;
+    double dyn = 0.0, post = 0.0;
+    for (size_t i = 0; i < n; ++i) {
+        float a = 0.f, b = 0.f;
+        HIPCHK(hipEventSynchronize(e->tev[3 * i + 2]));
+        HIPCHK(hipEventElapsedTime(&a, e->tev[3 * i], e->tev[3 * i + 1]));
+        HIPCHK(hipEventElapsedTime(&b, e->tev[3 * i + 1], e->tev[3 * i + 2]));
+        dyn += a; post += b;
+    }
+    if (dynamics_ms_avg) *dynamics_ms_avg = n ? dyn / (double)n : 0.0;
+    if (obs_ms_avg) *obs_ms_avg = n ? post / (double)n : 0.0;
+    if (steps) *steps = (int32_t)n;
+    e->tev_used = 0;
+    return PARC_OK;
 }
 
 extern "C" int parc_env_compute_obs(ParcEnv *e, const int64_t *ids, int32_t k, void *stream) {
