@@ -228,6 +228,25 @@ int parc_env_profile_step(ParcEnv *env, const float *action_dev, void *stream, i
 /* average duration of k_dynamics in the last parc_env_profile_step call (0 when dynamics is off) */
 float parc_env_last_dynamics_ms(ParcEnv *env);
 
+/* `env._episode_length = x` (dm_motion_recorder.py:55 raises it to 1000 s so that only the clip end finishes an episode) */
+int parc_env_set_episode_length(ParcEnv *env, float seconds);
+
+/* Recorder (IGParkourEnv.write_agent_states, ig_parkour_env.py:759-796; driven by dm_motion_recorder.py:52-121).
+ * The reference appends one row per recording env to Python lists every step; here the rows go to device ring buffers
+ * owned by the caller:
+ *   frames  [cap][N][PARC_REC_WIDTH] f32: root_pos 3 (env-local) | root_rot 4 (xyzw) | joint_rot (B-1) x 4 | contacts B
+ *           (contact = |F_b| > 1e-5, _get_char_state ig_parkour_env.py:664-685; the reference stores exp maps / dofs and
+ *           converts on save, the motion-terrain file format holds quaternions: file_io.py:8-16)
+ *   obs     [cap][N][obs_dim] f32 or NULL (record_obs)
+ *   count   [N] i32 rows written; writing [N] u8 (1 = this env is recording); n_writing [1] i32 number of such envs
+ * parc_env_record_frame appends the CURRENT state of every recording env (call it after reset for frame 0 and after
+ * every step, as the reference does) and ends the recording of envs whose done flag is FAIL; record_ref != 0 stores the
+ * reference-motion state instead of the character's (needs the ref_* mirrors of ParcEnvBuffers). */
+#define PARC_REC_WIDTH(B) (3 + 4 + 4 * ((B) - 1) + (B))
+int parc_env_record_bind(ParcEnv *env, float *frames_dev, float *obs_dev, int32_t cap, int32_t *count_dev, uint8_t *writing_dev,
+                         int32_t *n_writing_dev, int32_t record_ref);
+int parc_env_record_frame(ParcEnv *env, void *stream);
+
 /* Kernel timing over a run of ordinary parc_env_step calls (what bench.py reports as the roofline's kernel duration).
  * While enabled, every step records three events on the caller's stream (before the dynamics kernel, after it, after
  * the observation kernels); nothing synchronises.  parc_env_get_kernel_timing waits for the last step, returns the

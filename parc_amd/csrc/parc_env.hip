@@ -1118,6 +1118,10 @@ struct ParcEnv {
     size_t lds_bytes = 0;
     float last_dyn_ms = 0.f;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    float *rec_frames = nullptr, *rec_obs = nullptr;   // recorder ring buffers (caller-owned)
+    int rec_cap = 0, rec_ref = 0;
+    int *rec_count = nullptr, *rec_nwriting = nullptr;
+    unsigned char *rec_writing = nullptr;
     bool timing = false;               // parc_env_set_kernel_timing: record events around the kernels of every step
     std::vector<hipEvent_t> tev;       // 3 events per timed step (before dynamics, after dynamics, after the obs kernels)
     size_t tev_used = 0;
@@ -1483,6 +1487,81 @@ extern "C" int parc_env_step(ParcEnv *e, const float *action_dev, void *stream) 
     if (rc) return rc;
     if (tv) HIPCHK(hipEventRecord(tv[2], st));
     return launch_curriculum(e, st);
+}
+
+extern "C" int parc_env_set_episode_length(ParcEnv *e, float seconds) {
+    if (!e) return fail(PARC_ERR_INVALID, "null env");
+    if (!(seconds > 0.f)) return fail(PARC_ERR_INVALID, "episode length must be positive");
+    e->sp.episode_length = seconds;
+    return sync_params(e);
+}
+
+// Recorder: one 128-thread block per env appends that env's row (see include/parc_env.h).
+__global__ __launch_bounds__(128) void k_record(const DevTables *__restrict__ T, ParcEnvBuffers buf, int N, int B, int D, int obs_dim, float *frames,
+                                                float *obs_out, int cap, int *count, unsigned char *writing, int *n_writing, int use_ref) {
+    const int e = blockIdx.x, tid = threadIdx.x;
+    if (e >= N || !writing[e]) return;
+    const int t = count[e];
+    const int W = 3 + 4 + 4 * (B - 1) + B;
+    if (t < cap) {
+        float *row = frames + ((size_t)t * N + e) * W;
+        const float *rp = use_ref ? buf.ref_root_pos : buf.char_root_pos, *rr = use_ref ? buf.ref_root_rot : buf.char_root_rot;
+        if (tid < 3) row[tid] = rp[3 * (size_t)e + tid];
+        if (tid < 4) row[3 + tid] = rr[4 * (size_t)e + tid];
+        if (tid >= 1 && tid < B) {
+            Q4 q;
+            if (use_ref) q = *(const float4 *)(buf.ref_joint_rot + 4 * ((size_t)e * (B - 1) + tid - 1));
+            else q = joint_dof_to_rot(T->h.jtype[tid], T->h.axis[tid], buf.char_dof_pos + (size_t)e * D + T->h.dof_idx[tid]);
+            float *o = row + 7 + 4 * (tid - 1);
+            o[0] = q.x; o[1] = q.y; o[2] = q.z; o[3] = q.w;
+        }
+        if (tid < B) {
+            float c;
+            if (use_ref) c = buf.ref_contacts[(size_t)e * B + tid];
+            else {
+                const float *f = buf.contact_forces + 3 * ((size_t)e * B + tid);
+                c = sqrtf(f[0] * f[0] + f[1] * f[1] + f[2] * f[2]) > 1e-5f ? 1.f : 0.f;
+            }
+            row[7 + 4 * (B - 1) + tid] = c;
+        }
+        if (obs_out) {
+            const float *src = buf.obs + (size_t)e * obs_dim;
+            float *dst = obs_out + ((size_t)t * N + e) * obs_dim;
+            for (int i = tid; i < obs_dim; i += 128) dst[i] = src[i];
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const bool full = t >= cap;
+        if (!full) count[e] = t + 1;
+        if (buf.done[e] == PARC_DONE_FAIL || full) { // update_done ran before this: the row just written is the last one
+            writing[e] = 0;
+            atomicSub(n_writing, 1);
+        }
+    }
+}
+
+extern "C" int parc_env_record_bind(ParcEnv *e, float *frames_dev, float *obs_dev, int32_t cap, int32_t *count_dev, uint8_t *writing_dev,
+                                    int32_t *n_writing_dev, int32_t record_ref) {
+    if (!e) return fail(PARC_ERR_INVALID, "null env");
+    if (!frames_dev) { e->rec_frames = nullptr; e->rec_cap = 0; return PARC_OK; } // unbind
+    if (cap < 1 || !count_dev || !writing_dev || !n_writing_dev) return fail(PARC_ERR_INVALID, "recorder buffers are incomplete");
+    if (!e->bound) return fail(PARC_ERR_STATE, "bind_buffers must precede record_bind");
+    if (record_ref && (!e->sp.buf.ref_root_pos || !e->sp.buf.ref_root_rot || !e->sp.buf.ref_joint_rot || !e->sp.buf.ref_contacts))
+        return fail(PARC_ERR_STATE, "record_ref needs the ref_* mirrors to be bound");
+    e->rec_frames = frames_dev; e->rec_obs = obs_dev; e->rec_cap = cap; e->rec_count = count_dev; e->rec_writing = writing_dev;
+    e->rec_nwriting = n_writing_dev; e->rec_ref = record_ref ? 1 : 0;
+    return PARC_OK;
+}
+
+extern "C" int parc_env_record_frame(ParcEnv *e, void *stream) {
+    int rc = check_ready(e);
+    if (rc) return rc;
+    if (!e->rec_frames) return fail(PARC_ERR_STATE, "no recorder buffers bound");
+    hipLaunchKernelGGL(k_record, dim3(e->N), dim3(128), 0, (hipStream_t)stream, (const DevTables *)e->d_tab, e->sp.buf, e->N, e->B, e->D,
+                       e->obs_dim, e->rec_frames, e->rec_obs, e->rec_cap, e->rec_count, e->rec_writing, e->rec_nwriting, e->rec_ref);
+    HIPCHK(hipGetLastError());
+    return PARC_OK;
 }
 
 extern "C" int parc_env_set_kernel_timing(ParcEnv *e, int32_t enable) {

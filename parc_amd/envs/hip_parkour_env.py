@@ -11,12 +11,14 @@ from __future__ import annotations
 import ctypes as C
 import os
 import time
+import types
 from collections import OrderedDict
 
 import numpy as np
 import torch
 
 from parc_amd import lib as L
+from parc_amd import ms_file, terrain as terrain_mod
 from parc_amd.envs import base_env, scene as scene_mod
 from parc_amd.motion_lib import LoopMode
 
@@ -88,7 +90,7 @@ class HipParkourEnv(base_env.BaseEnv):
         self._scene = sc = scene_mod.build_scene(config, num_envs, _device_index(device), env_id_base, total_envs,
                                                  seed=seed, enable_dynamics=enable_dynamics)
         self._kin_char_model = sc.char_model
-        self._episode_length = env_config["episode_length"]
+        self._episode_length_val = env_config["episode_length"]
         self._control_freq = env_config["control_freq"]
         self._timestep = 1.0 / self._control_freq
         self._report_tracking_error = bool(env_config.get("report_tracking_error", False))
@@ -98,6 +100,10 @@ class HipParkourEnv(base_env.BaseEnv):
         self._rand_root_pos_offset_scale = env_config["rand_root_pos_offset_scale"]
         self._never_done = env_config.get("never_done", False)
         self._write_agent_states_flag = False
+        self._bypass_record_fail = False
+        self._record_ref = False
+        self._record_obs = False
+        self._rec = None
         self._motion_names = [c.name for c in sc.clips]
         self._key_body_ids = torch.tensor(sc.key_body_ids, dtype=torch.long, device=device)
         self._tar_obs_steps = torch.tensor(env_config.get("tar_obs_steps", [1]), dtype=torch.int, device=device)
@@ -252,6 +258,7 @@ class HipParkourEnv(base_env.BaseEnv):
         L.check(self._lib.parc_env_step(self._handle, a, self._stream()))
         if self._never_done:
             self._done_buf[:] = base_env.DoneFlags.NULL.value
+        self.write_agent_states()  # ig_parkour_env.py:686-696: after update_done, before the agent resets anything
         self._update_info()
         return self._obs_buf, self._reward_buf, self._done_buf, self._info
 
@@ -329,6 +336,109 @@ class HipParkourEnv(base_env.BaseEnv):
 
     def is_writing_agent_states(self):
         return self._write_agent_states_flag
+
+    # ---- recorder (ig_parkour_env.py:698-796, 1155-1181; driven by learning/dm_motion_recorder.py) ---------------
+    @property
+    def _episode_length(self):
+        return self._episode_length_val
+
+    @_episode_length.setter
+    def _episode_length(self, val):
+        self._episode_length_val = float(val)
+        if getattr(self, "_handle", None):
+            L.check(self._lib.parc_env_set_episode_length(self._handle, float(val)))
+
+    def build_agent_states_dict(self, name_suffix="", record_obs=False, max_frames=None):
+        """Start recording every env.  The reference keeps Python lists per env; here rows go to device ring buffers
+        ``[cap][N][78]`` (+ obs ``[cap][N][1312]``), cap = the longest clip at the control rate + margin."""
+        N, B, dev = self._num_envs, len(self._kin_char_model.get_body_names()), self._device
+        if max_frames is None:
+            max_frames = int(np.ceil(float(self._motion_lengths.max().item()) * self._control_freq)) + 8
+        W = 3 + 4 + 4 * (B - 1) + B
+        rec = types.SimpleNamespace()
+        rec.cap = int(max_frames)
+        rec.frames = torch.zeros(rec.cap, N, W, dtype=torch.float32, device=dev)
+        rec.obs = torch.zeros(rec.cap, N, self._obs_dim, dtype=torch.float32, device=dev) if record_obs else None
+        rec.count = torch.zeros(N, dtype=torch.int32, device=dev)
+        rec.writing = torch.ones(N, dtype=torch.uint8, device=dev)
+        rec.n_writing = torch.full((1,), N, dtype=torch.int32, device=dev)
+        rec.host_writing = np.ones(N, bool)
+        rec.obs_shapes = self._compute_obs(None, ret_obs_shapes=True) if record_obs else None
+        self._rec = rec
+        self._record_obs = record_obs
+        L.check(self._lib.parc_env_record_bind(self._handle, rec.frames.data_ptr(), rec.obs.data_ptr() if record_obs else None, rec.cap,
+                                               rec.count.data_ptr(), rec.writing.data_ptr(), rec.n_writing.data_ptr(),
+                                               int(bool(self._record_ref))))
+        self.set_write_agent_states_flag(True)
+        self._env_success_state = [False] * N
+        self._save_motion_name_suffix = name_suffix
+        print("recording agent motion..")
+
+    def is_writing_env_state(self, env_id):
+        return bool(self._rec.host_writing[env_id])
+
+    def set_writing_env_state(self, env_id, val):
+        """Only switching an env OFF before the roll-out starts is meaningful (dm_motion_recorder.py:66-68)."""
+        rec = self._rec
+        if bool(val) != bool(rec.host_writing[env_id]):
+            rec.host_writing[env_id] = bool(val)
+            rec.writing[env_id] = 1 if val else 0
+            rec.n_writing += 1 if val else -1
+
+    def set_env_success_state(self, env_id, val):
+        self._env_success_state[env_id] = val
+
+    def get_env_success_states(self):
+        return self._env_success_state
+
+    def write_agent_states(self):
+        """Append the current state of every recording env (one kernel), then save the envs that just finished."""
+        if not self.is_writing_agent_states() or self._rec is None:
+            return
+        rec = self._rec
+        L.check(self._lib.parc_env_record_frame(self._handle, self._stream()))
+        now = rec.writing.cpu().numpy().astype(bool)        # the recorder is host-driven like the reference's; one small D2H per step
+        finished = np.nonzero(rec.host_writing & ~now)[0]
+        rec.host_writing = now
+        self.set_write_agent_states_flag(bool(now.any()))
+        for env_id in finished:
+            env_id = int(env_id)
+            dm = self.get_dm_env()
+            motion_length = dm.get_env_motion_length(env_id).item()
+            curr_motion_time = dm.get_env_motion_time(env_id).item()
+            motion_name = dm.get_env_motion_name(env_id)
+            if not self._bypass_record_fail and curr_motion_time < motion_length - self._timestep * 2.0:
+                print("env", env_id, "failed to track motion", motion_name)
+                continue
+            self.set_env_success_state(env_id, True)
+            self.save_agent_states_to_file(env_id, motion_name + self._save_motion_name_suffix)
+
+    def save_agent_states_to_file(self, env_id, output_motion_name=None):
+        """ig_parkour_env.py:698-736: global xy, terrain sliced around the trajectory and localised, one file per env —
+        written in the motion-terrain container of file_io.py (what MotionLib loads), obs in ``misc_data``."""
+        rec = self._rec
+        n = int(rec.count[env_id].item())
+        rows = rec.frames[:n, env_id].cpu().numpy()
+        B = len(self._kin_char_model.get_body_names())
+        root_pos = rows[:, 0:3].copy()
+        root_pos[:, 0:2] += self._scene.env_offsets[env_id, 0:2]  # _get_global_xy_pos
+        gt = self._scene.grid.terrain
+        padding = round(1.0 // float(gt.dxdy[0])) * float(gt.dxdy[0])
+        sliced, local = terrain_mod.slice_terrain_around_motion(root_pos, gt, padding=padding)
+        md = ms_file.MSMotionData(root_pos=local.astype(np.float32), root_rot=rows[:, 3:7].copy(),
+                                  joint_rot=rows[:, 7:7 + 4 * (B - 1)].reshape(n, B - 1, 4).copy(),
+                                  body_contacts=rows[:, 7 + 4 * (B - 1):].copy(), fps=int(self._control_freq), loop_mode="CLAMP")
+        misc = None
+        if self._record_obs:
+            shapes = {k: {"use_normalizer": bool(v["use_normalizer"]), "shape": tuple(v["shape"])} for k, v in rec.obs_shapes.items()}
+            misc = {"obs": rec.obs[:n, env_id].cpu().numpy(), "obs_shapes": shapes, "hf_mask_inds": None}  # plain data only
+        if output_motion_name is None:
+            output_motion_name = "dm_motion_" + str(env_id).zfill(3)
+        os.makedirs(self._output_motion_dir, exist_ok=True)
+        path = os.path.join(self._output_motion_dir, output_motion_name + ".pkl")
+        ms_file.save_ms_file(ms_file.MSFileData(motion_data=md, terrain_data=sliced.to_ms_terrain_data(), misc_data=misc), path)
+        print("wrote motion data to", path)
+        print("num frames =", n)
 
     def _dm_extra_log_info(self):
         """dm_env.py:668-727 (per-motion fail rates + quantiles)."""

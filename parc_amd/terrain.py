@@ -61,6 +61,39 @@ class SubTerrain:
         return self.hf[idx[..., 0], idx[..., 1]]
 
 
+def slice_terrain_around_motion(frames_xyz, terrain: "SubTerrain", padding=1.0):
+    """terrain_util.py:1587-1642 (localize=True): the part of ``terrain`` under a recorded root trajectory plus ``padding``,
+    shifted so that the first frame is at xy = (0, 0) and stands at height hf = 0.  Returns (SubTerrain, localized xyz).
+    Same arithmetic as the torch code: fp32 tensors, ``torch.arange`` evaluated in double and stored as fp32."""
+    fr = np.asarray(frames_xyz, F32)
+    mn = np.array([fr[:, 0].min(), fr[:, 1].min()], F32) - F32(padding)
+    mx = np.array([fr[:, 0].max(), fr[:, 1].max()], F32) + F32(padding)
+    to_grid = lambda p: (np.rint((p - terrain.min_point) / terrain.dxdy) * terrain.dxdy + terrain.min_point).astype(F32)
+    g0, g1 = to_grid(mn), to_grid(mx)
+
+    def arange(start, end, step):  # torch.arange(float32 scalars): size and values computed in double
+        n = int(np.ceil((float(end) - float(start)) / float(step)))
+        return (float(start) + float(step) * np.arange(n, dtype=np.float64)).astype(F32)
+
+    xs = arange(g0[0], F32(g1[0] + terrain.dxdy[0]), terrain.dxdy[0])
+    ys = arange(g0[1], F32(g1[1] + terrain.dxdy[1]), terrain.dxdy[1])
+    pts = np.stack(np.meshgrid(xs, ys, indexing="ij"), axis=-1)
+    idx = terrain.get_grid_index(pts)
+    hf = terrain.hf[idx[..., 0], idx[..., 1]].copy()
+    hf_maxmin = terrain.hf_maxmin[idx[..., 0], idx[..., 1]].copy()
+    canon_xy = fr[0, 0:2].copy()
+    local = fr.copy()
+    local[:, 0:2] -= canon_xy
+    out = SubTerrain(hf.shape[0], hf.shape[1], terrain.dxdy[0], terrain.dxdy[1],
+                     float(g0[0]) - float(canon_xy[0]), float(g0[1]) - float(canon_xy[1]))
+    out.hf = hf
+    out.hf_maxmin = hf_maxmin
+    canon_z = out.get_hf_val_from_points(local[0, 0:2])
+    local[:, 2] -= canon_z
+    out.hf = (hf - canon_z).astype(F32)
+    return out, local
+
+
 def get_xy_points_cone(dx, num_neg, num_pos, num_rays_neg, num_rays_pos, angle_between_rays):
     """geom_util.py:251-272 in fp32 (torch.linspace's two-sided formula, then rotate_2d_vec per ray)."""
     dim = num_neg + num_pos + 1

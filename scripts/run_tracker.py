@@ -81,8 +81,11 @@ def run(args):
         Logger.print("Mean Return: {}".format(result["mean_return"]))
         Logger.print("Mean Episode Length: {}".format(result["mean_ep_len"]))
         Logger.print("Episodes: {}".format(result["num_eps"]))
+    elif mode == "record":  # PARC stage 4 (parc_4_phys_record.py -> run_tracker.run mode record -> record_dm_motions)
+        from parc_amd.learning.dm_motion_recorder import record_dm_motions
+        record_dm_motions(agent)
     else:
-        raise AssertionError("Unsupported mode: {} (record mode is not ported yet)".format(mode))
+        raise AssertionError("Unsupported mode: {}".format(mode))
 
 
 if __name__ == "__main__":

@@ -266,6 +266,25 @@ def gen_terrain(m):
          points=pts, grid_index=idx, hf_vals=vals)
 
 
+def gen_terrain_slice(m):
+    """terrain_util.slice_terrain_around_motion (terrain_util.py:1587-1660), as the recorder calls it
+    (ig_parkour_env.py:715-720): padding = round(1.0 // dx) * dx, localize=True."""
+    d = ms_file.load_ms_file(os.path.join(REF, "data/motion_terrains/TEASER_TERRAIN.pkl"), load_misc=False)
+    t = terrain_util.SubTerrain.from_ms_terrain_data(ref_file_io.MSTerrainData(**vars(d.terrain_data)), DEV)
+    g = torch.Generator().manual_seed(11)
+    out = {}
+    for i, (x0, y0, L) in enumerate([(3.0, 4.0, 40), (-1.0, 20.0, 90), (37.5, 37.9, 25)]):  # inside / over the low edge / over the high edge
+        steps = 0.08 * torch.randn(L, 2, generator=g) + torch.tensor([0.05, 0.02])
+        xy = torch.tensor([x0, y0]) + torch.cumsum(steps, 0)
+        z = 0.8 + 0.05 * torch.randn(L, generator=g)
+        frames = torch.cat([xy, z[:, None]], -1).to(torch.float32)
+        padding = round(1.0 // t.dxdy[0].item()) * t.dxdy[0].item()
+        st, loc = terrain_util.slice_terrain_around_motion(frames, t, padding=padding)
+        out.update({f"frames{i}": frames, f"padding{i}": np.float64(padding), f"hf{i}": st.hf, f"hf_maxmin{i}": st.hf_maxmin,
+                    f"min_point{i}": st.min_point, f"dims{i}": st.dims, f"local{i}": loc})
+    save("terrain_slice", hf=t.hf, hf_maxmin=t.hf_maxmin, min_point=t.min_point, dxdy=t.dxdy, **out)
+
+
 # ----------------------------------------------------------------------------------
 def env_config():
     cfg = yaml.safe_load(open(os.path.join(REF, "data/configs/tracker_config/dm_env_default.yaml")).read())
@@ -523,5 +542,6 @@ if __name__ == "__main__":
     gen_kin_ops(model)
     gen_motion_lib(model)
     gen_terrain(model)
+    gen_terrain_slice(model)
     gen_done_table()
     gen_env_step(model)

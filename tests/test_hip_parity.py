@@ -1,6 +1,8 @@
 """-m gpu: the HIP library (through its C-ABI / the HipParkourEnv shim) against the golden vectors of the real
 reference and against the CPU oracle.  Tolerance: 1e-5 absolute-or-relative fp32 (BASELINE.json north_star);
 integer outputs (done flags, frame indices, timesteps) exact."""
+import os
+
 import numpy as np
 import pytest
 
@@ -444,3 +446,95 @@ def test_dynamics_kernels_agree(tmp_path, monkeypatch):
                 assert np.abs(a - b).max() <= tol[nm], (it, kern, nm, np.abs(a - b).max())
             fa, fb = to_np(ref._char_contact_forces), to_np(envs[kern]._char_contact_forces)
             assert np.abs(fa - fb).max() <= 1.0 + 1e-3 * np.abs(fa).max(), (it, kern, np.abs(fa - fb).max())
+
+
+def test_recorder_writes_motion_terrain_files(tmp_path):
+    """Record mode (dm_motion_recorder.py:45-121): one env per motion, device ring buffers, files in the motion-terrain
+    container.  The recorded rows must equal the state / obs history of the roll-out and the file must load back."""
+    import torch
+    from gpu_helpers import default_config, write_motion_yaml, to_np
+    from parc_amd import ms_file, terrain as T
+    from parc_amd.envs.hip_parkour_env import HipParkourEnv
+    clips = ["sfu", "civilization"]
+    cfg = default_config()
+    cfg["env"]["dm"]["motion_file"] = write_motion_yaml(tmp_path, clips, [1.0, 1.0])
+    out_dir = str(tmp_path / "rec")
+    cfg["env"]["output_motion_dir"] = out_dir
+    n = 2
+    env = HipParkourEnv(cfg, n, "cuda:0", False, seed=3, enable_dynamics=True, mirror_ref_state=True)
+    env.set_rand_reset(False); env.set_demo_mode(True); env.set_rand_root_pos_offset_scale(0.0)
+    env._episode_length = 1000.0
+    env._bypass_record_fail = True      # an open-loop PD target falls before the clip ends; the file is written anyway
+    env.reset()
+    env.build_agent_states_dict("_dm", record_obs=True)
+    env.write_agent_states()
+    hist = {e: {"root": [to_np(env._char_root_pos)[e].copy()], "rot": [to_np(env._char_root_rot)[e].copy()],
+                "obs": [to_np(env._obs_buf)[e].copy()]} for e in range(n)}
+    alive = [True] * n
+    mids = to_np(env._motion_ids).copy()
+    for it in range(400):
+        if not env.is_writing_agent_states():
+            break
+        obs, r, done, info = env.step(env._ref_dof_pos.clone())
+        d = to_np(done)
+        for e in range(n):
+            if alive[e]:
+                hist[e]["root"].append(to_np(env._char_root_pos)[e].copy()); hist[e]["rot"].append(to_np(env._char_root_rot)[e].copy())
+                hist[e]["obs"].append(to_np(obs)[e].copy())
+                if d[e] == 1:
+                    alive[e] = False
+        env.reset_done()
+    assert not env.is_writing_agent_states() and not any(alive)
+    assert all(env.get_env_success_states())
+    for e in range(n):
+        name = clips[int(mids[e])] + "_dm.pkl"
+        f = ms_file.load_ms_file(os.path.join(out_dir, name))
+        k = len(hist[e]["root"])
+        md = f.motion_data
+        assert md.root_pos.shape == (k, 3) and md.root_rot.shape == (k, 4) and md.joint_rot.shape == (k, 14, 4) and md.body_contacts.shape == (k, 15)
+        assert md.fps == 30 and md.loop_mode == "CLAMP"
+        np.testing.assert_array_equal(md.root_rot, np.stack(hist[e]["rot"]))
+        np.testing.assert_array_equal(f.misc_data["obs"], np.stack(hist[e]["obs"]))
+        assert list(f.misc_data["obs_shapes"].keys()) == ["char_obs", "tar_obs", "tar_contacts", "char_contacts", "hf"]
+        # trajectory: global xy, localised so that frame 0 is at the origin standing on hf = 0 (terrain_util.py:1617-1642)
+        g = np.stack(hist[e]["root"]); g[:, 0:2] += env._scene.env_offsets[e, 0:2]
+        st, loc = T.slice_terrain_around_motion(g, env._scene.grid.terrain, padding=round(1.0 // 0.4) * float(env._scene.grid.terrain.dxdy[0]))
+        np.testing.assert_array_equal(md.root_pos, loc)
+        assert abs(md.root_pos[0, 0]) < 1e-6 and abs(md.root_pos[0, 1]) < 1e-6
+        np.testing.assert_array_equal(f.terrain_data.hf, st.hf)
+        tt = T.SubTerrain.from_ms_terrain_data(f.terrain_data)
+        assert tt.get_hf_val_from_points(md.root_pos[0, 0:2]) == 0.0
+        assert np.isin(md.body_contacts, [0.0, 1.0]).all() and np.abs(np.linalg.norm(md.joint_rot, axis=-1) - 1.0).max() < 1e-5
+
+
+def test_record_mode_driver(tmp_path):
+    """run_tracker --mode record == record_dm_motions(agent): an untrained policy fails every clip; with the fail filter
+    bypassed each env still writes <motion>_dm.pkl, and names with a number are binned into folders of 50."""
+    import torch
+    from gpu_helpers import default_config, write_motion_yaml
+    from parc_amd import ms_file
+    from parc_amd.envs.hip_parkour_env import HipParkourEnv
+    from parc_amd.learning.dm_ppo_agent import DMPPOAgent
+    from parc_amd.learning.dm_motion_recorder import record_dm_motions, organize_recorded_dm_motions
+    from parc_amd.util import path_loader
+    from conftest import DATA
+    clips = ["sfu", "civilization", "dec2024_teaser_717_1_opt_dm"]
+    cfg = default_config()
+    cfg["env"]["dm"]["motion_file"] = write_motion_yaml(tmp_path, clips, [1.0, 1.0, 1.0])
+    cfg["env"]["output_motion_dir"] = str(tmp_path / "rec")
+    env = HipParkourEnv(cfg, 3, "cuda:0", False, seed=4, enable_dynamics=True, mirror_ref_state=False)
+    env._bypass_record_fail = True
+    acfg = path_loader.load_config(os.path.join(DATA, "configs/tracker_config/dm_agent_default.yaml"))
+    agent = DMPPOAgent(acfg, env, "cuda:0")
+    ok, counts = record_dm_motions(agent, start_time_fractions=(0.1,), max_steps=600)
+    assert all(ok) and counts[0] == 3
+    assert env._episode_length == 1000.0 and env._demo_mode and not env._rand_reset
+    got = sorted(os.listdir(str(tmp_path / "rec")))
+    assert "sfu_dm.pkl" in got and "civilization_dm.pkl" in got
+    assert "dec2024_teaser_700_749" in got  # dec2024_teaser_717_1_opt_dm_dm.pkl -> bin 700..749 (dm_motion_recorder.py:13-43)
+    f = ms_file.load_ms_file(str(tmp_path / "rec" / "dec2024_teaser_700_749" / "dec2024_teaser_717_1_opt_dm_dm.pkl"))
+    assert f.motion_data.root_pos.shape[0] >= 2 and f.misc_data["obs"].shape[1] == 1312
+    # demo-mode resets start every clip at t = 0: frame 0 of the file is the clip's first pose
+    src = ms_file.load_ms_file(os.path.join(DATA, "motion_terrains", "dec2024_teaser_717_1_opt_dm.pkl"))
+    np.testing.assert_allclose(f.motion_data.root_rot[0], src.motion_data.root_rot[0], atol=1e-6)
+    np.testing.assert_allclose(f.motion_data.joint_rot[0], src.motion_data.joint_rot[0], atol=1e-5)

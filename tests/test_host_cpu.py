@@ -138,3 +138,19 @@ def test_path_loader_data_dir(monkeypatch, tmp_path):
     assert str(path_loader.resolve_path("$DATA_DIR/a/b.yaml")) == str(tmp_path / "a" / "b.yaml")
     monkeypatch.delenv("PARC_DATA_DIR")
     assert str(path_loader.resolve_path("$DATA_DIR/assets/humanoid.xml")).endswith("data/assets/humanoid.xml")
+
+
+def test_terrain_slice_matches_reference():
+    """slice_terrain_around_motion as the recorder uses it (terrain_util.py:1587-1642, ig_parkour_env.py:715-720)."""
+    from conftest import golden
+    from parc_amd import terrain as T
+    g = golden("terrain_slice")
+    t = T.SubTerrain(g["hf"].shape[0], g["hf"].shape[1], g["dxdy"][0], g["dxdy"][1], g["min_point"][0], g["min_point"][1])
+    t.hf = g["hf"].astype(np.float32); t.hf_maxmin = g["hf_maxmin"].astype(np.float32)
+    for i in range(3):
+        st, loc = T.slice_terrain_around_motion(g[f"frames{i}"], t, padding=float(g[f"padding{i}"]))
+        assert tuple(st.hf.shape) == tuple(g[f"hf{i}"].shape) == tuple(int(x) for x in g[f"dims{i}"])
+        np.testing.assert_array_equal(st.hf, g[f"hf{i}"])
+        np.testing.assert_array_equal(st.hf_maxmin, g[f"hf_maxmin{i}"])
+        np.testing.assert_array_equal(st.min_point, g[f"min_point{i}"])
+        np.testing.assert_array_equal(loc, g[f"local{i}"])
