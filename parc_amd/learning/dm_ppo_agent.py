@@ -19,7 +19,8 @@ import numpy as np
 import torch
 
 from parc_amd.envs import base_env
-from parc_amd.learning import dist_util, experience_buffer, normalizer, optimizer, ppo_model, return_tracker, rl_util
+from parc_amd.learning import (dist_util, experience_buffer, normalizer, optimizer, ppo_model, return_tracker, rl_util,
+                               tracking_error_tracker)
 from parc_amd.util.logger import Logger
 
 
@@ -49,6 +50,9 @@ class DMPPOAgent(torch.nn.Module):
         keys = list(self._env._info["rewards"].keys())
         self._train_return_tracker = return_tracker.ReturnTracker(self.get_num_envs(), device, keys)
         self._test_return_tracker = return_tracker.ReturnTracker(self.get_num_envs(), device, keys)
+        self._test_tracking_error_tracker = None
+        if getattr(env, "_report_tracking_error", False):  # dm_ppo_agent.py:25-28
+            self._test_tracking_error_tracker = tracking_error_tracker.TrackingErrorTracker(self.get_num_envs(), device)
         self._mode = AgentMode.TRAIN
         self._curr_obs = None
         self._curr_info = None
@@ -237,6 +241,9 @@ class DMPPOAgent(torch.nn.Module):
 
     def _rollout_test(self, num_episodes):
         self._test_return_tracker.reset()
+        tet = self._test_tracking_error_tracker
+        if tet is not None:
+            tet.reset()
         if num_episodes == 0:
             return {"mean_return": 0.0, "mean_ep_len": 0.0, "num_eps": 0}
         min_eps_per_env = int(np.ceil(num_episodes / self.get_num_envs()))
@@ -244,6 +251,8 @@ class DMPPOAgent(torch.nn.Module):
             action, _ = self._decide_action(self._curr_obs, self._curr_info)
             next_obs, r, done, next_info = self._step_env(action)
             self._test_return_tracker.update(next_info, done)
+            if tet is not None and "tracking_error" in next_info:
+                tet.update(next_info["tracking_error"], done)
             self._curr_obs, self._curr_info = self._reset_done_envs(done)
             if torch.all(self._test_return_tracker.get_eps_per_env() > min_eps_per_env - 1):
                 break
@@ -251,6 +260,8 @@ class DMPPOAgent(torch.nn.Module):
                 "mean_ep_len": self._test_return_tracker.get_mean_ep_len().item(),
                 "num_eps": self._test_return_tracker.get_episodes()}
         info.update(self._test_return_tracker.get_all_mean_returns())
+        if tet is not None:
+            info.update(tet.test_info())
         return info
 
     def step(self):

@@ -139,3 +139,30 @@ def test_data_parallel_two_ranks_gloo(tmp_path):
     assert int(r0["count"].item()) == 3 * 8 * 32 * 2
     assert torch.allclose(r0["fail"], torch.tensor([0.4, 0.6, 1.0])) and torch.allclose(r1["fail"], r0["fail"])
     assert r0["samples"] == 3 * 8 * 32 * 2
+
+
+def test_tracking_error_tracker_matches_reference_rule():
+    """tracking_error_tracker.py:72-125: per-env sums / episode length, running mean over finished episodes."""
+    import torch
+    from parc_amd.learning.tracking_error_tracker import TrackingErrorTracker
+    g = torch.Generator().manual_seed(0)
+    n = 6
+    trk = TrackingErrorTracker(n, "cpu")
+    # straightforward restatement with python lists
+    sums = [[0.0] * 7 for _ in range(n)]; lens = [0] * n; finished = []
+    for step in range(40):
+        te = torch.rand(n, 7, generator=g)
+        done = (torch.rand(n, generator=g) < 0.15).int() * (1 + (step % 3))
+        trk.update(te, done)
+        for e in range(n):
+            for k in range(7):
+                sums[e][k] += te[e, k].item()
+            lens[e] += 1
+            if done[e] != 0:
+                finished.append([s / lens[e] for s in sums[e]])
+                sums[e] = [0.0] * 7; lens[e] = 0
+    assert trk.get_episodes() == len(finished) > 5
+    want = torch.tensor(finished).mean(0)
+    assert torch.allclose(trk._mean, want, atol=1e-5)
+    info = trk.test_info()
+    assert abs(info["test_mean_dof_vel_tracking_err"] - want[4].item()) < 1e-5 and len(info) == 7
