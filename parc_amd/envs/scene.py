@@ -176,11 +176,14 @@ def build_scene(config: dict, num_envs: int, device_index: int = 0, env_id_base:
             assert dm_config["terrains_per_motion"] == 1
             hm = dm_config["heightmap"]
             grid = terrain.build_terrain_square(subs, hm["horizontal_scale"], hm["padding"])
+        elif build_mode == "wide":
+            hm = dm_config["heightmap"]
+            grid = terrain.build_terrain_wide(subs, hm["horizontal_scale"], hm["padding"], dm_config["terrains_per_motion"])
         elif build_mode == "file":
             grid = terrain.terrain_from_file(subs[0], num_envs)
             grid.motion_offsets = np.zeros((len(clips), 1, 2), np.float32)
         else:
-            raise ValueError("unsupported terrain build mode")  # "wide" is not ported
+            raise ValueError("unsupported terrain build mode")
         if save_path is not None:
             terrain.save_terrain(grid, save_path)
 

@@ -166,6 +166,44 @@ def build_terrain_square(terrains: List[SubTerrain], horizontal_scale: float, pa
     return TerrainGrid(g, offsets, 1)
 
 
+def build_terrain_wide(terrains: List[SubTerrain], horizontal_scale: float, padding: float, terrains_per_motion: int,
+                       x_offset: float = 0.0, y_offset: float = 0.0) -> TerrainGrid:
+    """dm_env.py:318-445 (``terrain_build_mode: wide``): motion i occupies a strip along x, its ``terrains_per_motion``
+    copies are stacked along y, ``padding`` on every side; cells between tiles stay at height 0.  Offsets are formed in
+    double and stored as fp32 (numpy 1.x semantics, as in build_terrain_square)."""
+    dx = float(horizontal_scale)
+    dy = dx
+    num_padding_cells = padding / dx
+    assert (round(num_padding_cells) - num_padding_cells) < 1e-5
+    num_padding_cells = int(num_padding_cells)
+    M, Tn = len(terrains), int(terrains_per_motion)
+    offsets = np.zeros((M, Tn, 2), F32)
+    gmin = np.zeros(2, F32)
+    gmax = np.zeros(2, F32)
+    og_y = y_offset
+    x_off = x_offset
+    for i, t in enumerate(terrains):
+        y_off = og_y
+        for j in range(Tn):
+            offsets[i, j, 0] = F32(x_off - float(t.min_point[0]))
+            offsets[i, j, 1] = F32(y_off - float(t.min_point[1]))
+            gmin[0] = min(float(gmin[0]), float(x_off)); gmin[1] = min(float(gmin[1]), float(y_off))
+            gmax[0] = max(float(gmax[0]), float(x_off + float(t.dims[0]) * dx))
+            gmax[1] = max(float(gmax[1]), float(y_off + float(t.dims[1]) * dx))
+            y_off += dy * int(t.dims[1]) + padding * 2.0
+        x_off += dx * int(t.dims[0]) + padding * 2.0
+    dims = np.rint((gmax - gmin) / F32(dx)).astype(np.int32)
+    g = SubTerrain(int(dims[0]), int(dims[1]), dx, dx, float(gmin[0]), float(gmin[1]))
+    sx = 0
+    for t in terrains:
+        sy = 0
+        for j in range(Tn):
+            g.hf[sx:sx + t.dims[0], sy:sy + t.dims[1]] = t.hf
+            sy += int(t.dims[1]) + 2 * num_padding_cells
+        sx += int(t.dims[0]) + 2 * num_padding_cells
+    return TerrainGrid(g, offsets, Tn)
+
+
 def terrain_from_file(terrain: SubTerrain, num_envs: int) -> TerrainGrid:
     """dm_env.py:105-155 (``terrain_build_mode: file``): the first clip's own terrain, zero offsets."""
     return TerrainGrid(terrain.copy(), np.zeros((max(num_envs, 1), 1, 2), F32), 1)

@@ -285,6 +285,29 @@ def gen_terrain_slice(m):
     save("terrain_slice", hf=t.hf, hf_maxmin=t.hf_maxmin, min_point=t.min_point, dxdy=t.dxdy, **out)
 
 
+def gen_terrain_wide(m):
+    """DeepMimicEnv.build_terrain_wide (dm_env.py:318-445): terrains stacked along x per motion and along y per copy."""
+    cfg = env_config()
+    dm = object.__new__(dm_env.DeepMimicEnv)
+    dm._device = DEV
+    dm._terrains_per_motion = 2
+    dm._mlib = make_mlib(m, ["sfu", "civilization", "TEASER_TERRAIN", "dec2024_teaser_717_1_opt_dm"])
+    _orig = terrain_util.SubTerrain.numpy_copy
+
+    def _numpy_copy64(self):  # numpy>=2 drift, see build_harness
+        t = _orig(self)
+        t.min_point = t.min_point.astype(np.float64)
+        return t
+
+    terrain_util.SubTerrain.numpy_copy = _numpy_copy64
+    try:
+        dm.build_terrain_wide(cfg["env"], "/tmp/parc_golden/terrain_wide.pkl")
+    finally:
+        terrain_util.SubTerrain.numpy_copy = _orig
+    save("terrain_wide", hf=dm._terrain.hf, min_point=dm._terrain.min_point, dxdy=dm._terrain.dxdy, dims=dm._terrain.dims,
+         motion_offsets=dm._dm_motion_offsets, clips=np.array(["sfu", "civilization", "TEASER_TERRAIN", "dec2024_teaser_717_1_opt_dm"]))
+
+
 # ----------------------------------------------------------------------------------
 def env_config():
     cfg = yaml.safe_load(open(os.path.join(REF, "data/configs/tracker_config/dm_env_default.yaml")).read())
@@ -543,5 +566,6 @@ if __name__ == "__main__":
     gen_motion_lib(model)
     gen_terrain(model)
     gen_terrain_slice(model)
+    gen_terrain_wide(model)
     gen_done_table()
     gen_env_step(model)

@@ -538,3 +538,39 @@ def test_record_mode_driver(tmp_path):
     src = ms_file.load_ms_file(os.path.join(DATA, "motion_terrains", "dec2024_teaser_717_1_opt_dm.pkl"))
     np.testing.assert_allclose(f.motion_data.root_rot[0], src.motion_data.root_rot[0], atol=1e-6)
     np.testing.assert_allclose(f.motion_data.joint_rot[0], src.motion_data.joint_rot[0], atol=1e-5)
+
+
+def test_wide_terrain_mode_with_two_copies_per_motion(tmp_path):
+    """terrain_build_mode: wide, terrains_per_motion: 2 (dm_env.py:318-445, 473-521): every env is moved onto the copy of
+    its motion's terrain that it drew (`_move_to_motion_terrain`, dm_env.py:554-565)."""
+    import torch
+    from gpu_helpers import default_config, write_motion_yaml, to_np
+    from parc_amd import ms_file
+    from parc_amd.envs.hip_parkour_env import HipParkourEnv
+    from conftest import DATA
+    clips = ["sfu", "civilization", "TEASER_TERRAIN"]
+    cfg = default_config()
+    cfg["env"]["dm"]["motion_file"] = write_motion_yaml(tmp_path, clips, [1.0, 1.0, 1.0])
+    cfg["env"]["dm"]["terrain_build_mode"] = "wide"
+    cfg["env"]["dm"]["terrains_per_motion"] = 2
+    n = 256
+    env = HipParkourEnv(cfg, n, "cuda:0", False, seed=8, enable_dynamics=False, mirror_ref_state=True)
+    env.set_rand_reset(False)   # every clip starts at t = 0
+    env.reset()
+    mid, tid = to_np(env._motion_ids).astype(int), to_np(env._motion_terrain_ids).astype(int)
+    assert set(np.unique(tid)) == {0, 1} and set(np.unique(mid)) == {0, 1, 2}
+    off = env._scene.grid.motion_offsets
+    assert off.shape == (3, 2, 2)
+    first = np.stack([ms_file.load_ms_file(os.path.join(DATA, "motion_terrains", c + ".pkl"), load_misc=False).motion_data.root_pos[0] for c in clips])
+    got = to_np(env._ref_root_pos)[:, 0:2] + env._scene.env_offsets[:, 0:2] - off[mid, tid]
+    assert np.abs(got - first[mid, 0:2]).max() < 1e-4
+    # the height rays see the copy's terrain: the cell under the root has the clip's own height there
+    t = env._scene.grid.terrain
+    g = to_np(env._ref_root_pos)[:, 0:2] + env._scene.env_offsets[:, 0:2]
+    h = t.get_hf_val_from_points(g)
+    src = [ms_file.load_ms_file(os.path.join(DATA, "motion_terrains", c + ".pkl"), load_misc=False) for c in clips]
+    from parc_amd import terrain as T
+    want = np.array([T.SubTerrain.from_ms_terrain_data(src[m].terrain_data).get_hf_val_from_points(first[m, 0:2]) for m in mid])
+    np.testing.assert_array_equal(h, want)
+    obs, r, d, info = env.step(None)
+    assert torch.isfinite(obs).all()

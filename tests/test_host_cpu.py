@@ -154,3 +154,17 @@ def test_terrain_slice_matches_reference():
         np.testing.assert_array_equal(st.hf_maxmin, g[f"hf_maxmin{i}"])
         np.testing.assert_array_equal(st.min_point, g[f"min_point{i}"])
         np.testing.assert_array_equal(loc, g[f"local{i}"])
+
+
+def test_build_terrain_wide_matches_reference():
+    """terrain_build_mode: wide (dm_env.py:318-445) against the reference's own output, 4 clips x 2 copies."""
+    import helpers
+    g = golden("terrain_wide")
+    subs = [terrain.SubTerrain.from_ms_terrain_data(ms_file.load_ms_file(helpers.clip_path(str(c)), load_misc=False).terrain_data)
+            for c in g["clips"]]
+    grid = terrain.build_terrain_wide(subs, 0.4, 0.4, 2)
+    assert grid.terrains_per_motion == 2
+    np.testing.assert_array_equal(grid.terrain.dims, g["dims"])
+    np.testing.assert_array_equal(grid.terrain.hf, g["hf"])
+    np.testing.assert_array_equal(grid.terrain.min_point, g["min_point"])
+    np.testing.assert_array_equal(grid.motion_offsets, g["motion_offsets"])
