@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--config", default=os.path.join(REPO, "data/configs/tracker_config/dm_env_default.yaml"))
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--motions", type=int, default=0,
+                    help="replicate the bundled clips to this many library entries (SURVEY 8(d) cfg 3: 1024); 0 = the 5 clips as they are")
     ap.add_argument("--dynamics", type=int, default=1, help="1: full step (rigid-body dynamics + contact), 0: kinematic step only")
     return ap.parse_args()
 
@@ -129,11 +131,31 @@ def main():
     from parc_amd.envs.hip_parkour_env import HipParkourEnv
     from parc_amd.util import path_loader
     cfg = path_loader.load_config(a.config)
+    if a.motions > 0:  # synthetic large library: names suffixed, same content (symlinks), weights unchanged
+        import tempfile, yaml
+        src = path_loader.load_config(str(path_loader.resolve_path(cfg["env"]["dm"]["motion_file"])))["motions"]
+        d = tempfile.mkdtemp(prefix=f"parc_bench_lib_r{rank}_")
+        ents = []
+        for i in range(a.motions):
+            m = src[i % len(src)]
+            f = str(path_loader.resolve_path(m["file"]))
+            dst = os.path.join(d, os.path.splitext(os.path.basename(f))[0] + f"_r{i:05d}.pkl")
+            os.symlink(f, dst)
+            ents.append({"file": dst, "weight": m.get("weight", 1.0)})
+        with open(os.path.join(d, "motions.yaml"), "w") as fh:
+            yaml.safe_dump({"motions": ents}, fh)
+        cfg["env"]["dm"]["motion_file"] = os.path.join(d, "motions.yaml")
+        cfg["env"]["dm"].pop("terrain_save_path", None)
     dyn = bool(a.dynamics)
     sys.stdout = sys.stderr if rank == 0 else open(os.devnull, "w")  # the only stdout line is the JSON below
     env = HipParkourEnv(cfg, a.envs, dev, False, env_id_base=rank * a.envs, total_envs=world * a.envs, seed=1234 + rank,
                         mirror_ref_state=False, enable_dynamics=dyn)
     dynamics_on = bool(env._scene.cfg.enable_dynamics)
+    mode = cfg["env"]["dm"].get("terrain_build_mode", "square")
+    ncl = len(env._scene.clips)
+    lib_desc = (f"{a.motions} library entries (the bundled clips replicated)" if a.motions > 0 else
+                (f"{ncl} bundled clips" if ncl > 1 else f"clip {env._scene.clips[0].name}")) + \
+               {"square": " on a square blocky grid", "wide": " on a wide blocky grid", "file": " on its own terrain"}.get(mode, "")
     D = env._char_dof_pos.shape[1]
     # untrained-policy actions (SURVEY §8(d) cfg 3): action-normalizer mean + N(0, 0.05^2) * std
     lo, hi = env._action_bound_low, env._action_bound_high
@@ -196,7 +218,7 @@ def main():
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": ("full step (dynamics + obs/reward/done)" if dynamics_on else "kinematic step (ref slerp + FK + 441-ray hf + obs + reward + done), no physics")
-                               + f", {a.envs} envs per GPU, 5 bundled clips on a square blocky grid, reset of finished envs included",
+                               + f", {a.envs} envs per GPU, " + lib_desc + ", reset of finished envs included",
                    "envs_per_gpu": a.envs, "total_envs": a.envs * world, "dynamics": dynamics_on, "parallelism": f"env-shard x{world}"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "kernel": kname, "kernel_ms": kms, "algorithmic_bytes_per_env_step": bytes_per,

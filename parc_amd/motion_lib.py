@@ -55,8 +55,14 @@ def fetch_motion_files(motion_file):
     return [motion_file], [1.0]
 
 
+_DECODED = {}  # realpath -> decoded file (datasets list the same file under many names / symlinks)
+
+
 def load_clip(path: str, weight: float = 1.0) -> Clip:
-    d = ms_file.load_ms_file(path, load_misc=False)
+    real = os.path.realpath(path)
+    d = _DECODED.get(real)
+    if d is None:
+        d = _DECODED[real] = ms_file.load_ms_file(path, load_misc=False)
     m = d.motion_data
     if m is None:
         raise ValueError(f"{path}: no motion_data")

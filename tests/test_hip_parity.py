@@ -185,7 +185,7 @@ def test_env_reset_vs_reference_golden(genv):
     assert np.array_equal(after, to_np(env._obs_buf))
 
 
-@pytest.mark.parametrize("n", [4096, 16384])
+@pytest.mark.parametrize("n", [1, 100, 4096, 16384])  # 1 and 100: ragged (not a multiple of the 64-env blocks)
 def test_env_step_vs_oracle_large(tmp_path, oracle, orc_char, n):
     """Same seeded state through the HIP step and the CPU oracle at cfg-2/cfg-3 env counts (from-FK bodies)."""
     import torch
@@ -409,13 +409,13 @@ def test_ppo_training_iterations_on_hip_env(tmp_path):
     assert "_model._actor_layers.0.weight" in sd and "_obs_norm._mean" in sd
 
 
-def test_dynamics_kernels_agree(tmp_path, monkeypatch):
+@pytest.mark.parametrize("n", [1, 100, 512])
+def test_dynamics_kernels_agree(tmp_path, monkeypatch, n):
     """The three dynamics kernels (wave-per-limb, chain-parallel, thread-per-env) integrate the same equations: one control
     step from the same state must agree to rounding.  Guards against miscompiles of the register-heavy wave kernel."""
     import torch
     from gpu_helpers import default_config, write_motion_yaml, to_np
     from parc_amd.envs.hip_parkour_env import HipParkourEnv
-    n = 512
     envs = {}
     for kern in ("wave", "coop", "thread"):
         monkeypatch.setenv("PARC_DYN_KERNEL", kern)
