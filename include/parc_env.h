@@ -231,6 +231,13 @@ float parc_env_last_dynamics_ms(ParcEnv *env);
 /* `env._episode_length = x` (dm_motion_recorder.py:55 raises it to 1000 s so that only the clip end finishes an episode) */
 int parc_env_set_episode_length(ParcEnv *env, float seconds);
 
+/* TD(lambda) returns of a rollout (rl_util.py:7-30; called from ppo_agent._build_train_data): one thread per env walks the
+ * T steps backwards,  ret[T-1] = r + g*nv,  ret[i] = r[i] + g*((1 - l_i)*nv[i] + l_i*ret[i+1]),  l_i = lambda*(1 - [done[i] != 0]).
+ * All arrays are device pointers laid out [T][N] (the experience buffer's layout); same fp32 operation order as the
+ * reference's Python loop, so results are bit-identical to it.  Needs no env handle. */
+int parc_td_lambda_return(const float *reward, const float *next_vals, const int32_t *done, float discount, float td_lambda,
+                          int32_t T, int32_t N, float *ret_out, void *stream);
+
 /* Recorder (IGParkourEnv.write_agent_states, ig_parkour_env.py:759-796; driven by dm_motion_recorder.py:52-121).
  * The reference appends one row per recording env to Python lists every step; here the rows go to device ring buffers
  * owned by the caller:

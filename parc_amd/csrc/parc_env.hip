@@ -1496,6 +1496,31 @@ extern "C" int parc_env_set_episode_length(ParcEnv *e, float seconds) {
     return sync_params(e);
 }
 
+__global__ void k_td_lambda(const float *__restrict__ r, const float *__restrict__ nv, const int *__restrict__ done, float g, float lam0, int T, int N,
+                            float *__restrict__ ret) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N) return;
+    size_t o = (size_t)(T - 1) * N + e;
+    float acc = r[o] + g * nv[o];
+    ret[o] = acc;
+    for (int i = T - 2; i >= 0; --i) {
+        o -= N;
+        const float reset = done[o] != PARC_DONE_NULL ? 1.0f : 0.0f;
+        const float lam = lam0 * (1.0f - reset);
+        acc = r[o] + g * ((1.0f - lam) * nv[o] + lam * acc);
+        ret[o] = acc;
+    }
+}
+
+extern "C" int parc_td_lambda_return(const float *reward, const float *next_vals, const int32_t *done, float discount, float td_lambda,
+                                     int32_t T, int32_t N, float *ret_out, void *stream) {
+    if (!reward || !next_vals || !done || !ret_out || T < 1 || N < 0) return fail(PARC_ERR_INVALID, "bad argument");
+    if (N == 0) return PARC_OK;
+    hipLaunchKernelGGL(k_td_lambda, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, reward, next_vals, done, discount, td_lambda, T, N, ret_out);
+    HIPCHK(hipGetLastError());
+    return PARC_OK;
+}
+
 // Recorder: one 128-thread block per env appends that env's row (see include/parc_env.h).
 __global__ __launch_bounds__(128) void k_record(const DevTables *__restrict__ T, ParcEnvBuffers buf, int N, int B, int D, int obs_dim, float *frames,
                                                 float *obs_out, int cap, int *count, unsigned char *writing, int *n_writing, int use_ref) {

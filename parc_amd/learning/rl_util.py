@@ -1,10 +1,14 @@
-"""TD(lambda) returns (``rl_util.py:7-30``): backward recursion over the rollout, lambda reset at episode ends."""
+"""TD(lambda) returns (``rl_util.py:7-30``): backward recursion over the rollout, lambda reset at episode ends.
+
+On a GPU the recursion is ONE kernel of the env library (``parc_td_lambda_return``: one thread per env, coalesced over the
+``[T][N]`` buffers, same fp32 operation order) instead of T Python iterations of ~8 elementwise launches each; the torch
+loop below is the CPU path of the unit tests and the statement of the arithmetic."""
 import torch
 
 from parc_amd.envs import base_env
 
 
-def compute_td_lambda_return(r, next_vals, done, discount, td_lambda):
+def compute_td_lambda_return_torch(r, next_vals, done, discount, td_lambda):
     assert r.shape == next_vals.shape
     ret = torch.zeros_like(r)
     reset = (done != base_env.DoneFlags.NULL.value).type(torch.float)
@@ -13,3 +17,18 @@ def compute_td_lambda_return(r, next_vals, done, discount, td_lambda):
         lam = td_lambda * (1.0 - reset[i])
         ret[i] = r[i] + discount * ((1.0 - lam) * next_vals[i] + lam * ret[i + 1])
     return ret
+
+
+def compute_td_lambda_return(r, next_vals, done, discount, td_lambda):
+    assert r.shape == next_vals.shape == done.shape
+    if not r.is_cuda:
+        return compute_td_lambda_return_torch(r, next_vals, done, discount, td_lambda)
+    from parc_amd import lib as L
+    lib = L.load()
+    T = r.shape[0]
+    r2, nv2 = r.reshape(T, -1).contiguous().float(), next_vals.reshape(T, -1).contiguous().float()
+    d2 = done.reshape(T, -1).contiguous().to(torch.int32)
+    ret = torch.empty_like(r2)
+    L.check(lib.parc_td_lambda_return(r2.data_ptr(), nv2.data_ptr(), d2.data_ptr(), float(discount), float(td_lambda), T, r2.shape[1],
+                                      ret.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    return ret.reshape(r.shape)

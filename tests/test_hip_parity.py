@@ -574,3 +574,17 @@ def test_wide_terrain_mode_with_two_copies_per_motion(tmp_path):
     np.testing.assert_array_equal(h, want)
     obs, r, d, info = env.step(None)
     assert torch.isfinite(obs).all()
+
+
+def test_td_lambda_kernel_bit_exact_vs_reference_loop():
+    """parc_td_lambda_return == rl_util.compute_td_lambda_return (rl_util.py:7-30), bit for bit, incl. T = 1 and done flags 1/2/3."""
+    import torch
+    from parc_amd.learning import rl_util
+    g = torch.Generator().manual_seed(1)
+    for T, N in [(1, 7), (32, 1000), (8, 4097)]:
+        r = torch.rand(T, N, generator=g)
+        nv = torch.randn(T, N, generator=g) * 5.0
+        done = (torch.rand(T, N, generator=g) < 0.1).int() * torch.randint(1, 4, (T, N), generator=g, dtype=torch.int32)
+        want = rl_util.compute_td_lambda_return_torch(r, nv, done, 0.99, 0.95)
+        got = rl_util.compute_td_lambda_return(r.cuda(), nv.cuda(), done.cuda(), 0.99, 0.95).cpu()
+        assert torch.equal(got, want), (T, N, (got - want).abs().max())
