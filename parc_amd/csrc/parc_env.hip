@@ -161,9 +161,8 @@ __global__ __launch_bounds__(64) void k_dynamics(const parcdyn::DynModel *__rest
 // active lanes; here 64 envs share every instruction.  Output: a 256-byte record per env (L2/Infinity-Cache
 // resident between the two launches).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_env_prep(const StepParams *__restrict__ Pp, const int64_t *__restrict__ env_ids,
+__global__ __launch_bounds__(64) void k_env_prep(const StepParams P, const int64_t *__restrict__ env_ids,
                                                  const int *__restrict__ env_ids32, const int *__restrict__ count_dev, int count) {
-    const StepParams &P = *Pp;
     if (count_dev) count = *count_dev;
     const int it = blockIdx.x * blockDim.x + threadIdx.x;
     if (it >= count) return;
@@ -205,9 +204,10 @@ __device__ __forceinline__ float wave_sum(float v) { // butterfly over the 64 la
 }
 
 template <int MODE>
-__global__ __launch_bounds__(64, 4) void k_env_post(const StepParams *__restrict__ Pp, const int64_t *__restrict__ env_ids,
+__global__ __launch_bounds__(64, 4) void k_env_post(const StepParams P, const int64_t *__restrict__ env_ids,
                                                  const int *__restrict__ env_ids32, const int *__restrict__ count_dev, int count) {
-    const StepParams &P = *Pp; // uniform, read-only: scalar loads where the value is used
+    // P arrives by value in the kernarg segment: its pointers are then known to be global (global_load / global_store
+    // instead of flat_*, which would also tie up the LDS wait counter), its scalars are scalar loads where they are used
     extern __shared__ __align__(16) float s_obs[]; // staged observation prefix [0, off_tarc)
     __shared__ HierTables s_tab;
     __shared__ float4 s_q[8][16];   // row r: quats 0..14 (0 = root), slot 15 = root position
@@ -1458,9 +1458,9 @@ static int launch_post(ParcEnv *e, int mode, const int64_t *ids, int count, hipS
                        const int *count_dev = nullptr) {
     if (count <= 0) return PARC_OK;
     const int grid = count;
-    hipLaunchKernelGGL(k_env_prep, dim3((count + 63) / 64), dim3(64), 0, st, (const StepParams *)e->d_sp, ids, ids32, count_dev, count);
-    if (mode == MODE_STEP) hipLaunchKernelGGL(k_env_post<MODE_STEP>, dim3(grid), dim3(64), e->lds_bytes, st, (const StepParams *)e->d_sp, ids, ids32, count_dev, count);
-    else hipLaunchKernelGGL(k_env_post<MODE_OBS>, dim3(grid), dim3(64), e->lds_bytes, st, (const StepParams *)e->d_sp, ids, ids32, count_dev, count);
+    hipLaunchKernelGGL(k_env_prep, dim3((count + 63) / 64), dim3(64), 0, st, e->sp, ids, ids32, count_dev, count);
+    if (mode == MODE_STEP) hipLaunchKernelGGL(k_env_post<MODE_STEP>, dim3(grid), dim3(64), e->lds_bytes, st, e->sp, ids, ids32, count_dev, count);
+    else hipLaunchKernelGGL(k_env_post<MODE_OBS>, dim3(grid), dim3(64), e->lds_bytes, st, e->sp, ids, ids32, count_dev, count);
     HIPCHK(hipGetLastError());
     return PARC_OK;
 }
