@@ -1090,7 +1090,6 @@ struct ParcEnv {
     int64_t F = 0;
     bool bound = false, have_motions = false, have_terrain = false;
     StepParams sp;
-    StepParams *d_sp = nullptr;
     float4 *d_prep = nullptr;
     parcdyn::DynModel h_dyn;
     parcdyn::DynModel *d_dyn = nullptr;
@@ -1131,7 +1130,7 @@ extern "C" const char *parc_last_error(void) { return g_err.c_str(); }
 extern "C" int parc_abi_version(void) { return PARC_ABI_VERSION; }
 
 static void free_dev(ParcEnv *e) {
-    void *ptrs[] = {e->d_sp, e->d_prep, e->d_dyn, e->d_coop, e->d_wave, e->d_tab, e->d_ray, e->d_env_off, e->d_hf, e->d_motion_off, e->d_records, e->d_meta, e->d_weights, e->d_fail,
+    void *ptrs[] = {e->d_prep, e->d_dyn, e->d_coop, e->d_wave, e->d_tab, e->d_ray, e->d_env_off, e->d_hf, e->d_motion_off, e->d_records, e->d_meta, e->d_weights, e->d_fail,
                     e->d_cdf, e->d_ema, e->d_done_list, e->d_done_key, e->d_chunk_count, e->d_motion_done, e->d_reset_count, e->d_tmp_mid, e->d_tmp_tid, e->d_tmp_t0, e->d_tmp_noise,
                     e->d_scratch_jr};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -1139,8 +1138,7 @@ static void free_dev(ParcEnv *e) {
     for (auto &ev : e->tev) if (ev) (void)hipEventDestroy(ev);
 }
 
-static int sync_params(ParcEnv *e) { // the kernels read StepParams through a device pointer
-    HIPCHK(hipMemcpy(e->d_sp, &e->sp, sizeof(StepParams), hipMemcpyHostToDevice));
+static int sync_params(ParcEnv *) { // StepParams travels by value with every launch: nothing to copy
     return PARC_OK;
 }
 
@@ -1230,7 +1228,6 @@ extern "C" int parc_env_create(const ParcEnvConfig *cfg, ParcEnv **out) {
     hipError_t r = hipSuccess;
     const size_t N = (size_t)e->N;
     if ((r = up((void **)&e->d_tab, &t, sizeof(t))) != hipSuccess ||
-        (r = up((void **)&e->d_sp, nullptr, sizeof(StepParams))) != hipSuccess ||
         (r = up((void **)&e->d_prep, nullptr, sizeof(float4) * 16 * N)) != hipSuccess ||
         (r = up((void **)&e->d_ray, cfg->ray_points_host, sizeof(float) * 2 * R)) != hipSuccess ||
         (r = up((void **)&e->d_env_off, cfg->env_offsets_host, sizeof(float) * 3 * N)) != hipSuccess ||
