@@ -369,6 +369,7 @@ class HipParkourEnv(base_env.BaseEnv):
         L.check(self._lib.parc_env_record_bind(self._handle, rec.frames.data_ptr(), rec.obs.data_ptr() if record_obs else None, rec.cap,
                                                rec.count.data_ptr(), rec.writing.data_ptr(), rec.n_writing.data_ptr(),
                                                int(bool(self._record_ref))))
+        os.makedirs(self._output_motion_dir, exist_ok=True)  # ig_parkour_env.py:56-58 does this when the env is built
         self.set_write_agent_states_flag(True)
         self._env_success_state = [False] * N
         self._save_motion_name_suffix = name_suffix

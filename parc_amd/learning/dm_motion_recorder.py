@@ -18,6 +18,8 @@ from parc_amd.learning.dm_ppo_agent import AgentMode
 def organize_recorded_dm_motions(source_dir, verbose=True):
     """dm_motion_recorder.py:13-43: ``<name>_<number>_*.pkl`` -> ``<name>_<lo>_<hi>/`` in bins of 50."""
     pattern = re.compile(r"^(.*?)_(\d+)_.*\.pkl$")
+    if not os.path.isdir(source_dir):
+        return
     for filename in os.listdir(source_dir):
         match = pattern.match(filename)
         if not match:
