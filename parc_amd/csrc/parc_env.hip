@@ -78,6 +78,7 @@ struct StepParams {
     int early_term, pose_term, track_root, track_root_h, tracking, body_pos_from_fk;
     // terrain
     const float *hf; int X, Y; float min_x, min_y, dx, dy; int tile_r;
+    float rdx, rdy;      // correctly rounded 1/dx, 1/dy (host): the ray loop divides by multiply + one exact correction
     unsigned tile_mul;   // idx / (2 tile_r + 1) == (idx * tile_mul) >> 16 for every tile cell (checked on the host)
     float tstep[8];      // control_dt * tar_obs_steps (fp32 product, mgdm_dm_util.py:232)
     // tables
@@ -127,6 +128,19 @@ __device__ __forceinline__ void joint_rot_to_dof(int type, const float *axis4, Q
         V3 e = quat_to_exp_map(q);
         out[0] = e.x; out[1] = e.y; out[2] = e.z;
     }
+}
+
+// Same value as cell_index (IEEE division), for a divisor whose correctly rounded reciprocal rd is known: q0 = RN(x*rd),
+// the residual x - d*q0 is exact in one fma, q = RN(q0 + r*rd) is the correctly rounded quotient (Markstein's
+// reciprocal-with-correction division; checked exhaustively against x/d on the CPU by tests/test_host_cpu.py for the
+// grid spacings in use).  3 instructions instead of the ~13 of the general sequence; used by the 441-ray loop.
+__device__ __forceinline__ int cell_index_rcp(float p, float mn, float d, float rd) {
+    const float x = p - mn;
+    const float q0 = x * rd;
+    const float r = fmaf(-d, q0, x);
+    float f = rintf(fmaf(r, rd, q0));
+    f = fminf(fmaxf(f, -1.0e9f), 1.0e9f);
+    return (int)f;
 }
 
 // terrain_util.py:146-152 — unclamped nearest cell (round half to even)
@@ -375,12 +389,12 @@ __global__ __launch_bounds__(64, 4) void k_env_post(const StepParams P, const in
                 if (r < P.R) {
                     const float px = (rayp[i].x * ch - rayp[i].y * sh) + gx; // rotate_2d_vec torch_util.py:651
                     const float py = (rayp[i].x * sh + rayp[i].y * ch) + gy;
-                    const int ix = cell_index(px, P.min_x, P.dx), iy = cell_index(py, P.min_y, P.dy);
-                    const int a = ix - ox, bq = iy - oy;
+                    const int ix = cell_index_rcp(px, P.min_x, P.dx, P.rdx), iy = cell_index_rcp(py, P.min_y, P.dy, P.rdy);
                     float h;
-                    if (a >= 0 && a < TW && bq >= 0 && bq < TW) {
+                    if (tr >= 0) { // the tile radius covers the whole fan by construction (parc_env_load_terrain): clamp, no fallback
+                        const int a = min(max(ix - ox, 0), TW - 1), bq = min(max(iy - oy, 0), TW - 1);
                         h = s_tile[a * TW + bq];
-                    } else { // outside the staged tile (cannot happen for the default fan; kept for safety)
+                    } else { // fan too wide for the LDS tile: direct gathers
                         const int cx = min(max(ix, 0), P.X - 1), cy = min(max(iy, 0), P.Y - 1);
                         h = P.hf[(size_t)cx * P.Y + cy];
                     }
@@ -1379,6 +1393,7 @@ extern "C" int parc_env_load_terrain(ParcEnv *e, const float *hf, int32_t X, int
     HIPCHK(hipMemcpy(e->d_motion_off, motion_offsets, sizeof(float) * 2 * (size_t)M * T, hipMemcpyHostToDevice));
     StepParams &sp = e->sp;
     sp.hf = e->d_hf; sp.X = X; sp.Y = Y; sp.min_x = min_x; sp.min_y = min_y; sp.dx = dx; sp.dy = dy; sp.T = T;
+    sp.rdx = (float)(1.0L / (long double)dx); sp.rdy = (float)(1.0L / (long double)dy);
     sp.motion_offsets = e->d_motion_off;
     e->T = T;
     // terrain tile radius: farthest ray sample in cells, +1 for the two independent roundings

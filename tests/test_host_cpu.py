@@ -168,3 +168,19 @@ def test_build_terrain_wide_matches_reference():
     np.testing.assert_array_equal(grid.terrain.hf, g["hf"])
     np.testing.assert_array_equal(grid.terrain.min_point, g["min_point"])
     np.testing.assert_array_equal(grid.motion_offsets, g["motion_offsets"])
+
+
+def test_ray_division_shortcut_is_exact():
+    """cell_index_rcp (parc_env.hip) == IEEE division for the grid spacings in use: every float numerator between 2^-7 and
+    2^13 metres, both signs (the ray loop's numerators are point - terrain min, within +-8 km)."""
+    import subprocess
+    here = os.path.join(REPO, "oracle")
+    subprocess.check_call(["make", "-C", here, "-s", "libdiv_check.so"])
+    lib = C.CDLL(os.path.join(here, "libdiv_check.so"))
+    lib.parc_check_rcp_division.restype = C.c_longlong
+    lib.parc_check_rcp_division.argtypes = [C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float)]
+    for d in (0.4, 0.1, 0.25, 0.3):
+        bad_x = C.c_float(0.0)
+        lo, hi = (2.0 ** -7, 2.0 ** 13) if d == 0.4 else (2.0 ** -3, 2.0 ** 9)
+        n = lib.parc_check_rcp_division(np.float32(d), lo, hi, C.byref(bad_x))
+        assert n == 0, (d, n, bad_x.value)
