@@ -21,12 +21,24 @@ class PPOModel(torch.nn.Module):
         self._critic_layers, _ = nets.build_net(config["critic_net"], {"obs": obs_space}, self._activation)
         self._critic_out = torch.nn.Linear(nets.calc_layers_out_size(self._critic_layers), 1)
         torch.nn.init.zeros_(self._critic_out.bias)
+        # Optional (not in the reference, off by default): run the two MLP trunks in bf16 on the matrix cores; the small heads
+        # (action distribution, value) and everything downstream stay fp32.  `model: {amp: bf16}` in the agent config.
+        amp = str(config.get("amp", "none")).lower()
+        assert amp in ("none", "bf16"), amp
+        self._amp_dtype = torch.bfloat16 if amp == "bf16" else None
+
+    def _trunk(self, layers, obs):
+        if self._amp_dtype is None or not obs.is_cuda:
+            return layers(obs)
+        with torch.autocast(device_type="cuda", dtype=self._amp_dtype):
+            h = layers(obs)
+        return h.float()
 
     def eval_actor(self, obs):
-        return self._action_dist(self._actor_layers(obs))
+        return self._action_dist(self._trunk(self._actor_layers, obs))
 
     def eval_critic(self, obs):
-        return self._critic_out(self._critic_layers(obs))
+        return self._critic_out(self._trunk(self._critic_layers, obs))
 
 
 DMPPOModel = PPOModel  # dm_ppo_model.py:12 — only the default MLP branch is supported
