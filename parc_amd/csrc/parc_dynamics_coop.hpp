@@ -118,8 +118,6 @@ __device__ unsigned long long g_dyn_stamps[16];
 #define DSTAMP(i) do { } while (0)
 #endif
 
-__device__ __forceinline__ void lds_put(float *dst, const float *src, int n) { for (int i = 0; i < n; ++i) dst[i] = src[i]; }
-
 __global__ __launch_bounds__(64, 1) void k_dynamics_coop(const DynModel *__restrict__ Mp, const CoopTables *__restrict__ Cp, DynTerrain T,
                                                          ParcEnvBuffers buf, const float *__restrict__ action,
                                                          const float *__restrict__ env_off_all, int N) {

@@ -176,9 +176,6 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
         if (brad < X.cell_min && bx >= 2 && bx < DYN_PATCH - 2 && by >= 2 && by < DYN_PATCH - 2 &&
             r.z + rootp.z + X.eo2 - brad > X.s_pmax[((bx - 2) * WV_PI + by - 2) * 64]) near = false;
     }
-#ifdef PARC_NO_CONTACT
-    near = false; // timing experiment only
-#endif
     if (near) {
         const int npt = W.npt[b], pt0 = W.pt0[b];
         for (int pi = 0; pi < npt; ++pi) {
