@@ -983,53 +983,127 @@ struct ResetParams {
     ParcEnvBuffers buf;
 };
 
-__global__ void k_reset_with(const ResetParams P, const int64_t *env_ids, const int *env_ids32, const int *count_dev, int k,
-                             const int *motion_ids, const int *terrain_ids, const float *t0, const float *xy_noise) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// 16 lanes per env (4 envs per wave): lane j owns quaternion / body j of the character, lane 15 the root position.  Same
+// arithmetic per quantity as the one-thread-per-env form it replaces (motion_frame_thread, joint_rot_to_dof, fk_thread),
+// so results are unchanged; the per-env serial chain (15 slerps + 14 exp maps + 15-body FK, ~7k instructions) becomes ~600.
+__global__ __launch_bounds__(64) void k_reset_with(const ResetParams P, const int64_t *env_ids, const int *env_ids32, const int *count_dev, int k,
+                                                   const int *motion_ids, const int *terrain_ids, const float *t0, const float *xy_noise) {
+    __shared__ float4 s_q[4][16];     // [g][0] root rotation, [g][j] joint j (j >= 1)
+    __shared__ float4 s_pos[4][16];   // FK: body positions
+    __shared__ float4 s_rot[4][16];   // FK: body rotations
+    __shared__ float s_dof[4][PARC_MAX_DOFS];
+    const int g = threadIdx.x >> 4, j = threadIdx.x & 15;
+    const int i = blockIdx.x * 4 + g;
     if (count_dev) k = *count_dev;
-    if (i >= k) return;
-    const int e = env_ids ? (int)env_ids[i] : (env_ids32 ? env_ids32[i] : i);
-    const int mid = motion_ids[i], tid = terrain_ids[i];
-    const float t = t0[i];
+    if ((int)blockIdx.x * 4 >= k) return; // the grid is sized for all envs, the list is usually short
+    const bool live = i < k;
     const int B = P.B, J = P.J, D = P.D;
-    P.buf.motion_ids[e] = mid;
-    P.buf.terrain_ids[e] = tid;
-    P.buf.time_offsets[e] = t;
-    // reference frame at t0 -> character state (mgdm_dm_util.py:89-100); ref_* mirrors when bound
-    FrameOut F;
-    F.root_pos = P.buf.char_root_pos; F.root_rot = P.buf.char_root_rot; F.root_vel = P.buf.char_root_vel;
-    F.root_ang_vel = P.buf.char_root_ang_vel; F.dof_vel = P.buf.char_dof_vel;
-    F.joint_rot = P.buf.ref_joint_rot ? P.buf.ref_joint_rot : P.scratch_jr;
-    F.contacts = P.buf.ref_contacts;
-    motion_frame_thread(P.records, P.meta[mid], t, B, J, D, (size_t)e, F);
-    const float *mo = P.motion_offsets + 2 * ((size_t)mid * P.T + tid);
-    const float ox = mo[0] - P.env_offsets[3 * e], oy = mo[1] - P.env_offsets[3 * e + 1];
-    float *crp = P.buf.char_root_pos + 3 * (size_t)e;
-    const float rx = crp[0] + ox, ry = crp[1] + oy, rz = crp[2];
-    const float *jr = F.joint_rot + 4 * (size_t)e * J;
-    float *dof = P.buf.char_dof_pos + (size_t)e * D;
-    for (int d = 0; d < D; ++d) dof[d] = 0.f;
-    for (int j = 1; j < B; ++j)
-        joint_rot_to_dof(P.tables->h.jtype[j], P.tables->h.axis[j], *(const float4 *)(jr + 4 * (j - 1)), dof + P.tables->h.dof_idx[j]);
-    if (P.buf.ref_root_pos) { float *o = P.buf.ref_root_pos + 3 * (size_t)e; o[0] = rx; o[1] = ry; o[2] = rz; }
-    if (P.buf.ref_root_rot) for (int c = 0; c < 4; ++c) P.buf.ref_root_rot[4 * (size_t)e + c] = P.buf.char_root_rot[4 * (size_t)e + c];
-    if (P.buf.ref_root_vel) for (int c = 0; c < 3; ++c) P.buf.ref_root_vel[3 * (size_t)e + c] = P.buf.char_root_vel[3 * (size_t)e + c];
-    if (P.buf.ref_root_ang_vel) for (int c = 0; c < 3; ++c) P.buf.ref_root_ang_vel[3 * (size_t)e + c] = P.buf.char_root_ang_vel[3 * (size_t)e + c];
-    if (P.buf.ref_dof_pos) for (int d = 0; d < D; ++d) P.buf.ref_dof_pos[(size_t)e * D + d] = dof[d];
-    if (P.buf.ref_dof_vel) for (int d = 0; d < D; ++d) P.buf.ref_dof_vel[(size_t)e * D + d] = P.buf.char_dof_vel[(size_t)e * D + d];
-    // add_noise_to_char_state (mgdm_dm_util.py:102-106): xy += scale * U(-1,1) (drawn by the caller / sampler)
-    crp[0] = rx + xy_noise[2 * i];
-    crp[1] = ry + xy_noise[2 * i + 1];
-    // rigid bodies: FK of the new state (PhysX would refresh them one sim step later); contact forces cleared
-    if (P.buf.char_body_pos) {
-        const float *rr = P.buf.char_root_rot + 4 * (size_t)e;
-        fk_thread(P.tables, B, mk3(crp[0], crp[1], crp[2]), mk4(rr[0], rr[1], rr[2], rr[3]), jr, P.buf.char_body_pos + 3 * (size_t)e * B, nullptr);
+    int e = 0, mid = 0, tid = 0;
+    float t = 0.f;
+    Blend bl; bl.i0 = 0; bl.i1 = 0; bl.b = 0.f;
+    MotionMeta meta = P.meta[0];
+    if (live) {
+        e = env_ids ? (int)env_ids[i] : (env_ids32 ? env_ids32[i] : i);
+        mid = motion_ids[i]; tid = terrain_ids[i]; t = t0[i];
+        meta = P.meta[mid];
+        bl = frame_blend(meta, t);
     }
-    if (P.buf.contact_forces) for (int c = 0; c < 3 * B; ++c) P.buf.contact_forces[(size_t)e * 3 * B + c] = 0.f;
-    P.buf.timestep[e] = 0;
-    if (P.buf.time) P.buf.time[e] = 0.f;
-    P.buf.done[e] = PARC_DONE_NULL;
-    if (P.buf.ep_num) P.buf.ep_num[e] += 1; // ig_parkour_env.py:826-827
+    const float4 *r0 = P.records + (size_t)bl.i0 * REC_F4, *r1 = P.records + (size_t)bl.i1 * REC_F4;
+    const float b = bl.b, a = 1.0f - b;
+    float *jr_out = P.buf.ref_joint_rot ? P.buf.ref_joint_rot : P.scratch_jr;
+    for (int d = j; d < D; d += 16) s_dof[g][d] = 0.f;
+    // ---- reference frame at t0 -> character state (mgdm_dm_util.py:89-100); ref_* mirrors when bound
+    float rx = 0.f, ry = 0.f, rz = 0.f;
+    if (live) {
+        if (j < B) {
+            const Q4 q = slerp(r0[j], r1[j], b);
+            s_q[g][j] = q;
+            if (j == 0) {
+                *(float4 *)(P.buf.char_root_rot + 4 * (size_t)e) = q;
+                if (P.buf.ref_root_rot) *(float4 *)(P.buf.ref_root_rot + 4 * (size_t)e) = q;
+            } else {
+                *(float4 *)(jr_out + 4 * ((size_t)e * J + j - 1)) = q;
+            }
+        }
+        // every lane forms the root position (the FK lanes need it too); lane 15 stores it
+        const float4 A = r0[REC_Q_POS], Bv = r1[REC_Q_POS];
+        float x = a * A.x + b * Bv.x, y = a * A.y + b * Bv.y, z = a * A.z + b * Bv.z;
+        if (meta.loop == PARC_LOOP_WRAP) {
+            const float ph = floorf(t / meta.length);
+            x = x + ph * meta.dx; y = y + ph * meta.dy; z = z + ph * meta.dz;
+        }
+        const float *mo = P.motion_offsets + 2 * ((size_t)mid * P.T + tid);
+        const float ox = mo[0] - P.env_offsets[3 * e], oy = mo[1] - P.env_offsets[3 * e + 1];
+        rx = x + ox; ry = y + oy; rz = z;
+        // velocities of frame idx0 (un-interpolated) and contacts, spread over the lanes
+        const float *v = (const float *)(r0 + REC_Q_VEL);
+        if (j < 3) {
+            P.buf.char_root_vel[3 * (size_t)e + j] = v[j];
+            P.buf.char_root_ang_vel[3 * (size_t)e + j] = v[4 + j];
+            if (P.buf.ref_root_vel) P.buf.ref_root_vel[3 * (size_t)e + j] = v[j];
+            if (P.buf.ref_root_ang_vel) P.buf.ref_root_ang_vel[3 * (size_t)e + j] = v[4 + j];
+        }
+        for (int d = j; d < D; d += 16) {
+            P.buf.char_dof_vel[(size_t)e * D + d] = v[8 + d];
+            if (P.buf.ref_dof_vel) P.buf.ref_dof_vel[(size_t)e * D + d] = v[8 + d];
+        }
+        if (P.buf.ref_contacts && j < B) {
+            const float *c0 = (const float *)(r0 + REC_Q_CONTACT), *c1 = (const float *)(r1 + REC_Q_CONTACT);
+            P.buf.ref_contacts[(size_t)e * B + j] = a * c0[j] + b * c1[j];
+        }
+    }
+    __syncthreads();
+    if (live && j >= 1 && j < B) joint_rot_to_dof(P.tables->h.jtype[j], P.tables->h.axis[j], s_q[g][j], &s_dof[g][P.tables->h.dof_idx[j]]);
+    __syncthreads();
+    // add_noise_to_char_state (mgdm_dm_util.py:102-106): xy += scale * U(-1,1) (drawn by the caller / sampler)
+    float cx = rx, cy = ry;
+    if (live) { cx = rx + xy_noise[2 * i]; cy = ry + xy_noise[2 * i + 1]; }
+    if (live) {
+        for (int d = j; d < D; d += 16) {
+            P.buf.char_dof_pos[(size_t)e * D + d] = s_dof[g][d];
+            if (P.buf.ref_dof_pos) P.buf.ref_dof_pos[(size_t)e * D + d] = s_dof[g][d];
+        }
+        if (j == 15) {
+            if (P.buf.ref_root_pos) { float *o = P.buf.ref_root_pos + 3 * (size_t)e; o[0] = rx; o[1] = ry; o[2] = rz; }
+            float *crp = P.buf.char_root_pos + 3 * (size_t)e;
+            crp[0] = cx; crp[1] = cy; crp[2] = rz;
+            P.buf.motion_ids[e] = mid;
+            P.buf.terrain_ids[e] = tid;
+            P.buf.time_offsets[e] = t;
+            P.buf.timestep[e] = 0;
+            if (P.buf.time) P.buf.time[e] = 0.f;
+            P.buf.done[e] = PARC_DONE_NULL;
+            if (P.buf.ep_num) P.buf.ep_num[e] += 1; // ig_parkour_env.py:826-827
+        }
+        if (P.buf.contact_forces) for (int c = j; c < 3 * B; c += 16) P.buf.contact_forces[(size_t)e * 3 * B + c] = 0.f;
+    }
+    // rigid bodies: FK of the new state (PhysX would refresh them one sim step later).  Lane j walks root -> body j; each
+    // body's pose is formed from its parent's exactly as fk_thread does, level by level.
+    if (P.buf.char_body_pos) {
+        if (live && j == 0) { s_rot[g][0] = s_q[g][0]; s_pos[g][0] = make_float4(cx, cy, rz, 0.f); }
+        __syncthreads();
+        int dj = 0; // depth of body j in the tree
+        if (j >= 1 && j < B) for (int q = j; q != 0; q = P.tables->h.parent[q]) ++dj;
+        for (int depth = 1; depth < B; ++depth) { // level by level: body j is formed once its parent is
+            if (live && j >= 1 && j < B) {
+                if (dj == depth) {
+                    const int p = P.tables->h.parent[j];
+                    const Q4 rp_ = s_rot[g][p];
+                    const float4 pp = s_pos[g][p];
+                    const V3 wt = quat_rotate(rp_, mk3(P.tables->h.lt[j][0], P.tables->h.lt[j][1], P.tables->h.lt[j][2]));
+                    s_pos[g][j] = make_float4(pp.x + wt.x, pp.y + wt.y, pp.z + wt.z, 0.f);
+                    s_rot[g][j] = quat_mul(rp_, quat_mul(mk4(P.tables->h.lr[j][0], P.tables->h.lr[j][1], P.tables->h.lr[j][2], P.tables->h.lr[j][3]), s_q[g][j]));
+                }
+            }
+            __syncthreads();
+            if (depth >= PARC_MAX_FK_DEPTH + 1) break;
+        }
+        if (live && j < B) {
+            float *bp = P.buf.char_body_pos + 3 * ((size_t)e * B + j);
+            const float4 pj = s_pos[g][j];
+            bp[0] = pj.x; bp[1] = pj.y; bp[2] = pj.z;
+        }
+    }
 }
 
 // ---- device RNG for resets: Philox4x32-10 ---------------------------------------------------------
@@ -1057,9 +1131,13 @@ __global__ __launch_bounds__(1024) void k_build_cdf(const float *fail_rates, con
     for (int m = b; m < eend; ++m) s += (double)(fmaxf(fail_rates[m], min_w) * motion_weights[m]);
     s_part[threadIdx.x] = s;
     __syncthreads();
-    if (threadIdx.x == 0) { double acc = 0.0; for (int i = 0; i < 1024; ++i) { double v = s_part[i]; s_part[i] = acc; acc += v; } }
-    __syncthreads();
-    double acc = s_part[threadIdx.x];
+    for (int off = 1; off < 1024; off <<= 1) { // inclusive block scan of the per-thread sums
+        const double v = threadIdx.x >= off ? s_part[threadIdx.x - off] : 0.0;
+        __syncthreads();
+        s_part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    double acc = threadIdx.x > 0 ? s_part[threadIdx.x - 1] : 0.0; // exclusive prefix of this thread's range
     for (int m = b; m < eend; ++m) { acc += (double)(fmaxf(fail_rates[m], min_w) * motion_weights[m]); cdf[m] = (float)acc; }
 }
 
@@ -1651,7 +1729,7 @@ extern "C" int parc_env_reset_with(ParcEnv *e, const int64_t *ids, int32_t k, co
     if (!mids || !tids || !t0 || !noise || (k > 0 && !ids)) return fail(PARC_ERR_INVALID, "null sample array");
     const int n = k < 0 ? e->N : k;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_reset_with, dim3((n + 63) / 64), dim3(64), 0, st, make_reset_params(e), k < 0 ? nullptr : ids, (const int *)nullptr,
+    hipLaunchKernelGGL(k_reset_with, dim3((n + 3) / 4), dim3(64), 0, st, make_reset_params(e), k < 0 ? nullptr : ids, (const int *)nullptr,
                        (const int *)nullptr, n, mids, tids, t0, noise);
     HIPCHK(hipGetLastError());
     return launch_post(e, MODE_OBS, k < 0 ? nullptr : ids, n, st);
@@ -1684,7 +1762,7 @@ extern "C" int parc_env_reset_done(ParcEnv *e, void *stream) {
     hipLaunchKernelGGL(k_reset_sample, dim3((n + 127) / 128), dim3(128), 0, st, (const int64_t *)nullptr, e->d_done_list, e->d_reset_count, n, e->M,
                        e->T, e->d_cdf, e->d_meta, (unsigned long long)e->cfg.seed, e->reset_calls++, e->cfg.rand_reset, e->cfg.demo_mode,
                        e->cfg.rand_root_pos_offset_scale, e->d_start_frac, e->d_tmp_mid, e->d_tmp_tid, e->d_tmp_t0, e->d_tmp_noise);
-    hipLaunchKernelGGL(k_reset_with, dim3((n + 63) / 64), dim3(64), 0, st, make_reset_params(e), (const int64_t *)nullptr, e->d_done_list,
+    hipLaunchKernelGGL(k_reset_with, dim3((n + 3) / 4), dim3(64), 0, st, make_reset_params(e), (const int64_t *)nullptr, e->d_done_list,
                        e->d_reset_count, n, e->d_tmp_mid, e->d_tmp_tid, e->d_tmp_t0, e->d_tmp_noise);
     HIPCHK(hipGetLastError());
     return launch_post(e, MODE_OBS, nullptr, n, st, e->d_done_list, e->d_reset_count);
