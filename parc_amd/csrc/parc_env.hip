@@ -980,6 +980,7 @@ struct ResetParams {
     const float4 *records; const MotionMeta *meta; const float *motion_offsets; const float *env_offsets;
     const DevTables *tables;
     float *scratch_jr;  // [N][J][4] when ref_joint_rot is not bound
+    float4 *prep;       // [N][16]: the record k_env_prep would write for the reset envs (saves that launch)
     ParcEnvBuffers buf;
 };
 
@@ -1055,6 +1056,22 @@ __global__ __launch_bounds__(64) void k_reset_with(const ResetParams P, const in
     __syncthreads();
     if (live && j >= 1 && j < B) joint_rot_to_dof(P.tables->h.jtype[j], P.tables->h.axis[j], s_q[g][j], &s_dof[g][P.tables->h.dof_idx[j]]);
     __syncthreads();
+    // the record k_env_prep forms from the NEW state (same expressions: heading terms from the root rotation, character
+    // joint quaternions from the stored dofs), so the observation pass that follows needs no prep launch
+    if (live && j < B) {
+        float4 *out = P.prep + (size_t)e * 16;
+        if (j == 0) {
+            const float heading = calc_heading(s_q[g][0]);
+            const Q4 hinv = heading_quat_inv(heading);
+            out[0] = make_float4(cosf(heading), sinf(heading), hinv.z, hinv.w);
+        } else {
+            const int ty = P.tables->h.jtype[j], di = P.tables->h.dof_idx[j];
+            Q4 q = mk4(0.f, 0.f, 0.f, 1.f);
+            if (ty == PARC_JOINT_HINGE) q = axis_angle_to_quat(mk3(P.tables->h.axis[j][0], P.tables->h.axis[j][1], P.tables->h.axis[j][2]), s_dof[g][di]);
+            else if (ty == PARC_JOINT_SPHERICAL) q = exp_map_to_quat(mk3(s_dof[g][di], s_dof[g][di + 1], s_dof[g][di + 2]));
+            out[j] = q;
+        }
+    }
     // add_noise_to_char_state (mgdm_dm_util.py:102-106): xy += scale * U(-1,1) (drawn by the caller / sampler)
     float cx = rx, cy = ry;
     if (live) { cx = rx + xy_noise[2 * i]; cy = ry + xy_noise[2 * i + 1]; }
@@ -1545,10 +1562,10 @@ static int launch_curriculum(ParcEnv *e, hipStream_t st) {
 }
 
 static int launch_post(ParcEnv *e, int mode, const int64_t *ids, int count, hipStream_t st, const int *ids32 = nullptr,
-                       const int *count_dev = nullptr) {
+                       const int *count_dev = nullptr, bool prep_done = false) {
     if (count <= 0) return PARC_OK;
     const int grid = count;
-    hipLaunchKernelGGL(k_env_prep, dim3((count + 63) / 64), dim3(64), 0, st, e->sp, ids, ids32, count_dev, count);
+    if (!prep_done) hipLaunchKernelGGL(k_env_prep, dim3((count + 63) / 64), dim3(64), 0, st, e->sp, ids, ids32, count_dev, count);
     if (mode == MODE_STEP) hipLaunchKernelGGL(k_env_post<MODE_STEP>, dim3(grid), dim3(64), e->lds_bytes, st, e->sp, ids, ids32, count_dev, count);
     else hipLaunchKernelGGL(k_env_post<MODE_OBS>, dim3(grid), dim3(64), e->lds_bytes, st, e->sp, ids, ids32, count_dev, count);
     HIPCHK(hipGetLastError());
@@ -1716,7 +1733,7 @@ static ResetParams make_reset_params(ParcEnv *e) {
     ResetParams rp;
     rp.B = e->B; rp.J = e->J; rp.D = e->D; rp.T = e->T; rp.N = e->N;
     rp.records = e->d_records; rp.meta = e->d_meta; rp.motion_offsets = e->d_motion_off; rp.env_offsets = e->d_env_off;
-    rp.tables = e->d_tab; rp.scratch_jr = e->d_scratch_jr; rp.buf = e->sp.buf;
+    rp.tables = e->d_tab; rp.scratch_jr = e->d_scratch_jr; rp.prep = e->d_prep; rp.buf = e->sp.buf;
     return rp;
 }
 
@@ -1732,7 +1749,7 @@ extern "C" int parc_env_reset_with(ParcEnv *e, const int64_t *ids, int32_t k, co
     hipLaunchKernelGGL(k_reset_with, dim3((n + 3) / 4), dim3(64), 0, st, make_reset_params(e), k < 0 ? nullptr : ids, (const int *)nullptr,
                        (const int *)nullptr, n, mids, tids, t0, noise);
     HIPCHK(hipGetLastError());
-    return launch_post(e, MODE_OBS, k < 0 ? nullptr : ids, n, st);
+    return launch_post(e, MODE_OBS, k < 0 ? nullptr : ids, n, st, nullptr, nullptr, /*prep_done=*/true);
 }
 
 extern "C" int parc_env_reset(ParcEnv *e, const int64_t *ids, int32_t k, void *stream) {
@@ -1765,7 +1782,7 @@ extern "C" int parc_env_reset_done(ParcEnv *e, void *stream) {
     hipLaunchKernelGGL(k_reset_with, dim3((n + 3) / 4), dim3(64), 0, st, make_reset_params(e), (const int64_t *)nullptr, e->d_done_list,
                        e->d_reset_count, n, e->d_tmp_mid, e->d_tmp_tid, e->d_tmp_t0, e->d_tmp_noise);
     HIPCHK(hipGetLastError());
-    return launch_post(e, MODE_OBS, nullptr, n, st, e->d_done_list, e->d_reset_count);
+    return launch_post(e, MODE_OBS, nullptr, n, st, e->d_done_list, e->d_reset_count, /*prep_done=*/true);
 }
 
 extern "C" int parc_env_get_fail_rates(ParcEnv *e, float *out, int32_t M) {
