@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--motions", type=int, default=0,
                     help="replicate the bundled clips to this many library entries (SURVEY 8(d) cfg 3: 1024); 0 = the 5 clips as they are")
+    ap.add_argument("--graph", type=int, default=0,
+                    help="1: step + reset_done as one hipGraph launch (parc_env_step_reset_graph); kernel timings are then taken from a short separate run")
     ap.add_argument("--dynamics", type=int, default=1, help="1: full step (rigid-body dynamics + contact), 0: kinematic step only")
     return ap.parse_args()
 
@@ -164,8 +166,11 @@ def main():
     env.reset()
 
     def one_step(i):
-        env.step(actions[i & 3])
-        env.reset_done()
+        if a.graph:
+            env.step_and_reset_done(actions[i & 3] if dynamics_on else None)
+        else:
+            env.step(actions[i & 3])
+            env.reset_done()
 
     for i in range(a.warmup):
         one_step(i)
@@ -191,7 +196,14 @@ def main():
     dms, pms, nst = C.c_double(), C.c_double(), C.c_int32()
     L.check(env._lib.parc_env_get_kernel_timing(env._handle, C.byref(dms), C.byref(pms), C.byref(nst)))
     L.check(env._lib.parc_env_set_kernel_timing(env._handle, 0))
-    assert nst.value == a.steps
+    if a.graph:  # events are not part of the captured graph: time the kernels over 20 ordinary steps instead
+        L.check(env._lib.parc_env_set_kernel_timing(env._handle, 1))
+        for i in range(20):
+            env.step(actions[i & 3]); env.reset_done()
+        L.check(env._lib.parc_env_get_kernel_timing(env._handle, C.byref(dms), C.byref(pms), C.byref(nst)))
+        L.check(env._lib.parc_env_set_kernel_timing(env._handle, 0))
+    else:
+        assert nst.value == a.steps
     dyn_ms, post_ms = float(dms.value), float(pms.value)
     # HBM traffic of k_env_post from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs;
     # FETCH_SIZE doubled per the gfx950 correction).  Only valid for the configuration it was collected on.
@@ -219,7 +231,8 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": ("full step (dynamics + obs/reward/done)" if dynamics_on else "kinematic step (ref slerp + FK + 441-ray hf + obs + reward + done), no physics")
                                + f", {a.envs} envs per GPU, " + lib_desc + ", reset of finished envs included",
-                   "envs_per_gpu": a.envs, "total_envs": a.envs * world, "dynamics": dynamics_on, "parallelism": f"env-shard x{world}"},
+                   "envs_per_gpu": a.envs, "total_envs": a.envs * world, "dynamics": dynamics_on, "parallelism": f"env-shard x{world}",
+                   "launch": "hipGraph (step + reset_done)" if a.graph else "stream launches"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "kernel": kname, "kernel_ms": kms, "algorithmic_bytes_per_env_step": bytes_per,
                      "note": ("the dynamics kernel is VALU-issue / latency bound (rigid-body recursion, ~47k VALU instructions per wave at 1 wave per SIMD; "

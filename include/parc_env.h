@@ -231,6 +231,14 @@ float parc_env_last_dynamics_ms(ParcEnv *env);
 /* `env._episode_length = x` (dm_motion_recorder.py:55 raises it to 1000 s so that only the clip end finishes an episode) */
 int parc_env_set_episode_length(ParcEnv *env, float seconds);
 
+/* One control step INCLUDING the reset of the envs it finished (== parc_env_step + parc_env_reset_done) as a single
+ * hipGraph launch: the ~10 dependent kernel launches are captured once and replayed, which removes the host-side launch
+ * cost that dominates below ~10 000 envs.  The action is read from the buffer bound with parc_env_bind_action (write the
+ * policy output there); the graph is re-captured automatically when a setter changes something it bakes in.  Kernel
+ * timing events and the recorder are not part of the graph: use parc_env_step for those. */
+int parc_env_bind_action(ParcEnv *env, const float *action_dev);
+int parc_env_step_reset_graph(ParcEnv *env, void *stream);
+
 /* TD(lambda) returns of a rollout (rl_util.py:7-30; called from ppo_agent._build_train_data): one thread per env walks the
  * T steps backwards,  ret[T-1] = r + g*nv,  ret[i] = r[i] + g*((1 - l_i)*nv[i] + l_i*ret[i+1]),  l_i = lambda*(1 - [done[i] != 0]).
  * All arrays are device pointers laid out [T][N] (the experience buffer's layout); same fp32 operation order as the

@@ -1140,7 +1140,10 @@ __device__ __forceinline__ void philox4(unsigned long long seed, unsigned long l
 }
 
 // weights = clamp(fail_rate, min_w) * motion_weight (dm_env.py:487-490) -> inclusive CDF (one block)
-__global__ __launch_bounds__(1024) void k_build_cdf(const float *fail_rates, const float *motion_weights, float min_w, int M, float *cdf) {
+__global__ __launch_bounds__(1024) void k_build_cdf(const float *fail_rates, const float *motion_weights, float min_w, int M, float *cdf,
+                                                    unsigned long long *reset_calls) {
+    if (threadIdx.x == 0) *reset_calls += 1ull; // index of this reset call for the Philox stream (device-side, so that a
+                                                // captured graph replays with a fresh index every time)
     __shared__ double s_part[1024];
     const int per = (M + 1023) / 1024;
     const int b = threadIdx.x * per, eend = min(M, b + per);
@@ -1159,12 +1162,13 @@ __global__ __launch_bounds__(1024) void k_build_cdf(const float *fail_rates, con
 }
 
 __global__ void k_reset_sample(const int64_t *env_ids, const int *env_ids32, const int *count_dev, int k, int M, int T, const float *cdf, const MotionMeta *meta,
-                               unsigned long long seed, unsigned long long call, int rand_reset, int demo_mode, float noise_scale,
+                               unsigned long long seed, const unsigned long long *call_dev, int rand_reset, int demo_mode, float noise_scale,
                                const float *start_frac, int *motion_ids, int *terrain_ids, float *t0, float *xy_noise) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (count_dev) k = *count_dev;
     if (i >= k) return;
     const int e = env_ids ? (int)env_ids[i] : (env_ids32 ? env_ids32[i] : i);
+    const unsigned long long call = *call_dev;
     float u[4], v[4];
     philox4(seed, call, (unsigned)e * 2u, u);
     philox4(seed, call, (unsigned)e * 2u + 1u, v);
@@ -1221,7 +1225,10 @@ struct ParcEnv {
     int nchunks = 0;
     int *d_tmp_mid = nullptr, *d_tmp_tid = nullptr;
     float *d_tmp_t0 = nullptr, *d_tmp_noise = nullptr, *d_scratch_jr = nullptr, *d_start_frac = nullptr;
-    unsigned long long reset_calls = 0;
+    unsigned long long *d_reset_calls = nullptr;   // device counter of sampling resets (Philox call index)
+    const float *action_bound = nullptr;           // parc_env_bind_action
+    hipGraphExec_t graph_exec = nullptr;           // parc_env_step_reset_graph
+    bool graph_dirty = true;
     int grid_waves = 0;
     size_t lds_bytes = 0;
     float last_dyn_ms = 0.f;
@@ -1240,14 +1247,16 @@ extern "C" int parc_abi_version(void) { return PARC_ABI_VERSION; }
 
 static void free_dev(ParcEnv *e) {
     void *ptrs[] = {e->d_prep, e->d_dyn, e->d_coop, e->d_wave, e->d_tab, e->d_ray, e->d_env_off, e->d_hf, e->d_motion_off, e->d_records, e->d_meta, e->d_weights, e->d_fail,
-                    e->d_cdf, e->d_ema, e->d_done_list, e->d_done_key, e->d_chunk_count, e->d_motion_done, e->d_reset_count, e->d_tmp_mid, e->d_tmp_tid, e->d_tmp_t0, e->d_tmp_noise,
+                    e->d_cdf, e->d_ema, e->d_done_list, e->d_done_key, e->d_chunk_count, e->d_motion_done, e->d_reset_count, e->d_reset_calls, e->d_tmp_mid, e->d_tmp_tid, e->d_tmp_t0, e->d_tmp_noise,
                     e->d_scratch_jr};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &ev : e->ev) if (ev) (void)hipEventDestroy(ev);
     for (auto &ev : e->tev) if (ev) (void)hipEventDestroy(ev);
+    if (e->graph_exec) (void)hipGraphExecDestroy(e->graph_exec);
 }
 
-static int sync_params(ParcEnv *) { // StepParams travels by value with every launch: nothing to copy
+static int sync_params(ParcEnv *e) { // StepParams travels by value with every launch; a captured graph holds a copy
+    e->graph_dirty = true;
     return PARC_OK;
 }
 
@@ -1345,6 +1354,7 @@ extern "C" int parc_env_create(const ParcEnvConfig *cfg, ParcEnv **out) {
         (r = up((void **)&e->d_done_key, nullptr, sizeof(int) * N)) != hipSuccess ||
         (r = up((void **)&e->d_chunk_count, nullptr, sizeof(int) * 1024)) != hipSuccess ||
         (r = up((void **)&e->d_reset_count, nullptr, sizeof(int))) != hipSuccess ||
+        (r = up((void **)&e->d_reset_calls, nullptr, sizeof(unsigned long long))) != hipSuccess ||
         (r = up((void **)&e->d_tmp_mid, nullptr, sizeof(int) * N)) != hipSuccess ||
         (r = up((void **)&e->d_tmp_tid, nullptr, sizeof(int) * N)) != hipSuccess ||
         (r = up((void **)&e->d_tmp_t0, nullptr, sizeof(float) * N)) != hipSuccess ||
@@ -1509,6 +1519,7 @@ extern "C" int parc_env_load_terrain(ParcEnv *e, const float *hf, int32_t X, int
     const int stage_pad = (sp.off_tarc + 3) & ~3;
     e->lds_bytes = sizeof(float) * (size_t)stage_pad;
     e->have_terrain = true;
+    e->graph_dirty = true;
     return sync_params(e);
 }
 
@@ -1524,6 +1535,7 @@ extern "C" int parc_env_bind_buffers(ParcEnv *e, const ParcEnvBuffers *b) {
         return fail(PARC_ERR_INVALID, "quaternion buffers must be 16-byte aligned");
     e->sp.buf = *b;
     e->bound = true;
+    e->graph_dirty = true;
     return sync_params(e);
 }
 
@@ -1760,9 +1772,9 @@ extern "C" int parc_env_reset(ParcEnv *e, const int64_t *ids, int32_t k, void *s
     if (k > 0 && !ids) return fail(PARC_ERR_INVALID, "env_ids is NULL");
     const int n = k < 0 ? e->N : k;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_build_cdf, dim3(1), dim3(1024), 0, st, e->d_fail, e->d_weights, e->cfg.min_motion_weight, e->M, e->d_cdf);
+    hipLaunchKernelGGL(k_build_cdf, dim3(1), dim3(1024), 0, st, e->d_fail, e->d_weights, e->cfg.min_motion_weight, e->M, e->d_cdf, e->d_reset_calls);
     hipLaunchKernelGGL(k_reset_sample, dim3((n + 127) / 128), dim3(128), 0, st, k < 0 ? nullptr : ids, (const int *)nullptr, (const int *)nullptr, n, e->M, e->T, e->d_cdf, e->d_meta,
-                       (unsigned long long)e->cfg.seed, e->reset_calls++, e->cfg.rand_reset, e->cfg.demo_mode,
+                       (unsigned long long)e->cfg.seed, (const unsigned long long *)e->d_reset_calls, e->cfg.rand_reset, e->cfg.demo_mode,
                        e->cfg.rand_root_pos_offset_scale, e->d_start_frac, e->d_tmp_mid, e->d_tmp_tid, e->d_tmp_t0, e->d_tmp_noise);
     HIPCHK(hipGetLastError());
     return parc_env_reset_with(e, k < 0 ? nullptr : ids, k, e->d_tmp_mid, e->d_tmp_tid, e->d_tmp_t0, e->d_tmp_noise, stream);
@@ -1775,14 +1787,55 @@ extern "C" int parc_env_reset_done(ParcEnv *e, void *stream) {
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     const int n = e->N;
-    hipLaunchKernelGGL(k_build_cdf, dim3(1), dim3(1024), 0, st, e->d_fail, e->d_weights, e->cfg.min_motion_weight, e->M, e->d_cdf);
+    hipLaunchKernelGGL(k_build_cdf, dim3(1), dim3(1024), 0, st, e->d_fail, e->d_weights, e->cfg.min_motion_weight, e->M, e->d_cdf, e->d_reset_calls);
     hipLaunchKernelGGL(k_reset_sample, dim3((n + 127) / 128), dim3(128), 0, st, (const int64_t *)nullptr, e->d_done_list, e->d_reset_count, n, e->M,
-                       e->T, e->d_cdf, e->d_meta, (unsigned long long)e->cfg.seed, e->reset_calls++, e->cfg.rand_reset, e->cfg.demo_mode,
+                       e->T, e->d_cdf, e->d_meta, (unsigned long long)e->cfg.seed, (const unsigned long long *)e->d_reset_calls, e->cfg.rand_reset, e->cfg.demo_mode,
                        e->cfg.rand_root_pos_offset_scale, e->d_start_frac, e->d_tmp_mid, e->d_tmp_tid, e->d_tmp_t0, e->d_tmp_noise);
     hipLaunchKernelGGL(k_reset_with, dim3((n + 3) / 4), dim3(64), 0, st, make_reset_params(e), (const int64_t *)nullptr, e->d_done_list,
                        e->d_reset_count, n, e->d_tmp_mid, e->d_tmp_tid, e->d_tmp_t0, e->d_tmp_noise);
     HIPCHK(hipGetLastError());
     return launch_post(e, MODE_OBS, nullptr, n, st, e->d_done_list, e->d_reset_count, /*prep_done=*/true);
+}
+
+// ---- whole control step as one hipGraph launch ----------------------------------------------------------------------
+// step + reset_done are ~10 dependent launches; at a few thousand envs the host-side launch cost exceeds the kernels.
+// The sequence is captured once on a private stream and replayed with one hipGraphLaunch.  Everything a kernel argument
+// bakes in is either fixed per handle (buffers, tables), re-captured when it changes (graph_dirty), or read from device
+// memory (done count, reset-call index, the bound action buffer).
+extern "C" int parc_env_bind_action(ParcEnv *e, const float *action_dev) {
+    if (!e) return fail(PARC_ERR_INVALID, "null env");
+    e->action_bound = action_dev;
+    e->graph_dirty = true;
+    return PARC_OK;
+}
+
+extern "C" int parc_env_step_reset_graph(ParcEnv *e, void *stream) {
+    int rc = check_ready(e);
+    if (rc) return rc;
+    if (e->cfg.enable_dynamics && !e->action_bound) return fail(PARC_ERR_STATE, "parc_env_bind_action must precede the graph step when dynamics is on");
+    if (e->graph_dirty || !e->graph_exec) {
+        if (e->graph_exec) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }
+        hipStream_t cs = nullptr;
+        HIPCHK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+        hipGraph_t graph = nullptr;
+        hipError_t err = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+        if (err == hipSuccess) {
+            const bool timing = e->timing;
+            e->timing = false; // events are not captured
+            rc = parc_env_step(e, e->action_bound, cs);
+            if (!rc) rc = parc_env_reset_done(e, cs);
+            e->timing = timing;
+            err = hipStreamEndCapture(cs, &graph);
+        }
+        if (err == hipSuccess && !rc) err = hipGraphInstantiate(&e->graph_exec, graph, nullptr, nullptr, 0);
+        if (graph) (void)hipGraphDestroy(graph);
+        (void)hipStreamDestroy(cs);
+        if (rc) return rc;
+        if (err != hipSuccess) { e->graph_exec = nullptr; return fail(PARC_ERR_HIP, std::string("graph capture failed: ") + hipGetErrorString(err)); }
+        e->graph_dirty = false;
+    }
+    HIPCHK(hipGraphLaunch(e->graph_exec, (hipStream_t)stream));
+    return PARC_OK;
 }
 
 extern "C" int parc_env_get_fail_rates(ParcEnv *e, float *out, int32_t M) {
@@ -1813,12 +1866,14 @@ extern "C" int parc_env_get_motion_info(ParcEnv *e, float *lengths, float *weigh
 extern "C" int parc_env_set_rand_reset(ParcEnv *e, int32_t rand_reset, int32_t demo_mode, float scale) {
     if (!e) return fail(PARC_ERR_INVALID, "null env");
     e->cfg.rand_reset = rand_reset; e->cfg.demo_mode = demo_mode; e->cfg.rand_root_pos_offset_scale = scale;
+    e->graph_dirty = true;
     return PARC_OK;
 }
 
 extern "C" int parc_env_set_start_time_fraction(ParcEnv *e, const float *frac_dev) {
     if (!e) return fail(PARC_ERR_INVALID, "null env");
     e->d_start_frac = const_cast<float *>(frac_dev);
+    e->graph_dirty = true;
     return PARC_OK;
 }
 

@@ -262,6 +262,22 @@ class HipParkourEnv(base_env.BaseEnv):
         self._update_info()
         return self._obs_buf, self._reward_buf, self._done_buf, self._info
 
+    def step_and_reset_done(self, action):
+        """``step(action)`` followed by ``reset_done()`` as ONE hipGraph launch (launch-bound sizes: a few thousand envs).
+        Returns the same persistent tensors; the rows of finished envs already hold the first observation of their new
+        episode, ``done`` / ``reward`` still describe the step that ended."""
+        if self._rec is not None and self.is_writing_agent_states():
+            raise RuntimeError("the recorder needs step() + reset_done(); the graph step does not record")
+        if action is not None:
+            if getattr(self, "_action_buf", None) is None:
+                self._action_buf = torch.zeros_like(self._char_dof_pos)
+                L.check(self._lib.parc_env_bind_action(self._handle, self._action_buf.data_ptr()))
+            if action.data_ptr() != self._action_buf.data_ptr():
+                self._action_buf.copy_(action)
+        L.check(self._lib.parc_env_step_reset_graph(self._handle, self._stream()))
+        self._update_info()
+        return self._obs_buf, self._reward_buf, self._done_buf, self._info
+
     def _update_info(self):
         """ig_parkour_env.py:1108-1116 + the reward dict of :1012-1044 (views, not clones: the agent copies them)."""
         rt = self._reward_terms

@@ -588,3 +588,43 @@ def test_td_lambda_kernel_bit_exact_vs_reference_loop():
         want = rl_util.compute_td_lambda_return_torch(r, nv, done, 0.99, 0.95)
         got = rl_util.compute_td_lambda_return(r.cuda(), nv.cuda(), done.cuda(), 0.99, 0.95).cpu()
         assert torch.equal(got, want), (T, N, (got - want).abs().max())
+
+
+@pytest.mark.parametrize("dyn", [False, True])
+def test_graph_step_equals_step_plus_reset_done(tmp_path, dyn):
+    """parc_env_step_reset_graph replays exactly the launches of step + reset_done: state, obs, rewards, done flags, fail
+    rates and the device RNG stream stay bit-identical over many steps (incl. after a setter forces a re-capture)."""
+    import torch
+    from gpu_helpers import default_config, write_motion_yaml, to_np
+    from helpers import CLIPS4
+    from parc_amd.envs.hip_parkour_env import HipParkourEnv
+    n = 3000
+    envs = []
+    for _ in range(2):
+        cfg = default_config()
+        cfg["env"]["dm"]["motion_file"] = write_motion_yaml(tmp_path, CLIPS4, [1, 2, 3, 4])
+        env = HipParkourEnv(cfg, n, "cuda:0", False, seed=21, enable_dynamics=dyn, mirror_ref_state=True)
+        env.reset()
+        envs.append(env)
+    a, b = envs
+    g = torch.Generator(device="cuda:0"); g.manual_seed(5)
+    names = ["_obs_buf", "_reward_buf", "_done_buf", "_char_root_pos", "_char_root_rot", "_char_dof_pos", "_char_dof_vel", "_char_rigid_body_pos",
+             "_motion_ids", "_motion_terrain_ids", "_motion_time_offsets", "_timestep_buf", "_ep_num_buf", "_ref_root_pos", "_char_contact_forces"]
+    total_done = 0
+    for it in range(60):
+        if it == 30:  # a setter that is baked into the captured kernels: both paths must pick it up
+            a._episode_length = 0.5; b._episode_length = 0.5
+        if dyn:
+            act = (a._char_dof_pos + 0.3 * torch.randn(a._char_dof_pos.shape, device="cuda:0", generator=g)).contiguous()
+        else:
+            act = None
+            noise = 0.03 * torch.randn(a._char_root_pos.shape, device="cuda:0", generator=g)
+            a._char_root_pos += noise; b._char_root_pos += noise
+        a.step(act); a.reset_done()
+        b.step_and_reset_done(act)
+        for nm in names:
+            x, y = to_np(getattr(a, nm)), to_np(getattr(b, nm))
+            assert np.array_equal(x, y), (it, nm, np.abs(x.astype(np.float64) - y.astype(np.float64)).max())
+    total_done = int(a._ep_num_buf.sum().item()) - n   # every reset bumps ep_num; the first one was reset()
+    assert total_done > 500, total_done
+    assert np.array_equal(a.get_fail_rates().numpy(), b.get_fail_rates().numpy())
