@@ -186,6 +186,10 @@ int parc_env_load_terrain(ParcEnv *env, const float *hf_host, int32_t X, int32_t
                           float dx, float dy, const float *motion_offsets_host, int32_t M, int32_t T);
 /* IGCharEnv._build_sim_tensors / IGParkourEnv._build_data_buffers tensor views */
 int parc_env_bind_buffers(ParcEnv *env, const ParcEnvBuffers *bufs);
+/* The state view (SURVEY 8(b) "get_state / set_state"): the character, reference and bookkeeping state lives in the
+ * caller's device buffers bound above; this returns those pointers, reading them is get_state, writing them before
+ * parc_env_step is set_state (that is how the kinematic configuration injects the character state). */
+int parc_env_get_buffers(ParcEnv *env, ParcEnvBuffers *out);
 
 /* IGEnv.step (ig_env.py:66-84): clip action -> [dynamics] -> _post_physics_step.  action_dev [N][D]
  * may be NULL when enable_dynamics == 0. */

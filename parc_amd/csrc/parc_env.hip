@@ -1608,6 +1608,13 @@ extern "C" int parc_env_step(ParcEnv *e, const float *action_dev, void *stream) 
     return launch_curriculum(e, st);
 }
 
+extern "C" int parc_env_get_buffers(ParcEnv *e, ParcEnvBuffers *out) {
+    if (!e || !out) return fail(PARC_ERR_INVALID, "null argument");
+    if (!e->bound) return fail(PARC_ERR_STATE, "bind_buffers first");
+    *out = e->sp.buf;
+    return PARC_OK;
+}
+
 extern "C" int parc_env_set_episode_length(ParcEnv *e, float seconds) {
     if (!e) return fail(PARC_ERR_INVALID, "null env");
     if (!(seconds > 0.f)) return fail(PARC_ERR_INVALID, "episode length must be positive");
