@@ -171,10 +171,13 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
     v3 fsum = mk(0.f, 0.f, 0.f);
     const float brad = W.brad[b];
     bool near = true;
+    float hmax = 3.0e38f; // highest column any sphere of this body can touch (+inf when the 5x5 window is not applicable)
     {
         const int bx = cell_of(r.x + rootp.x + X.eo0, T.min_x, T.dx) - X.pox, by = cell_of(r.y + rootp.y + X.eo1, T.min_y, T.dy) - X.poy;
-        if (brad < X.cell_min && bx >= 2 && bx < DYN_PATCH - 2 && by >= 2 && by < DYN_PATCH - 2 &&
-            r.z + rootp.z + X.eo2 - brad > X.s_pmax[((bx - 2) * WV_PI + by - 2) * 64]) near = false;
+        if (brad < X.cell_min && bx >= 2 && bx < DYN_PATCH - 2 && by >= 2 && by < DYN_PATCH - 2) {
+            hmax = X.s_pmax[((bx - 2) * WV_PI + by - 2) * 64];
+            if (r.z + rootp.z + X.eo2 - brad > hmax) near = false;
+        }
     }
     if (near) {
         const int npt = W.npt[b], pt0 = W.pt0[b];
@@ -183,6 +186,7 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
             const v3 x = r + mulv(R, mk(M.col_pos[kp][0], M.col_pos[kp][1], M.col_pos[kp][2]));
             const v3 g = mk(x.x + rootp.x + X.eo0, x.y + rootp.y + X.eo1, x.z + rootp.z + X.eo2);
             const float rad = M.col_r[kp];
+            if (g.z - rad > hmax) continue; // e.g. the upper corners of a foot that stands on the ground
             const int ix = cell_of(g.x, T.min_x, T.dx), iy = cell_of(g.y, T.min_y, T.dy);
             const int pa_ = ix - X.pox, pb_ = iy - X.poy;
             const bool inp = pa_ >= 1 && pa_ < DYN_PATCH - 1 && pb_ >= 1 && pb_ < DYN_PATCH - 1;
