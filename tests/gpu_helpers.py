@@ -12,7 +12,11 @@ GOLDEN_WEIGHTS = [1.0, 1.5, 2.0, 2.5]
 
 
 def default_config():
-    return copy.deepcopy(path_loader.load_config(os.path.join(DATA, "configs/tracker_config/dm_env_default.yaml")))
+    """dm_env_default.yaml with the physics switched off: the parity tests inject the character state (the kinematic
+    configuration); tests of the dynamics pass ``enable_dynamics=True`` to the env."""
+    cfg = copy.deepcopy(path_loader.load_config(os.path.join(DATA, "configs/tracker_config/dm_env_default.yaml")))
+    cfg["env"].setdefault("hip", {})["enable_dynamics"] = False
+    return cfg
 
 
 def write_motion_yaml(tmp_dir, clip_names, weights):
