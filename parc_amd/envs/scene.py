@@ -238,7 +238,7 @@ def build_scene(config: dict, num_envs: int, device_index: int = 0, env_id_base:
     for d in range(D):
         cfg.action_low[d] = float(act_low[d])
         cfg.action_high[d] = float(act_high[d])
-    dyn = env_config.get("hip", {}).get("enable_dynamics", False) if enable_dynamics is None else enable_dynamics
+    dyn = env_config.get("hip", {}).get("enable_dynamics", True) if enable_dynamics is None else enable_dynamics  # the reference always simulates
     cfg.enable_dynamics = int(bool(dyn))
     cfg.body_pos_from_fk = int(env_config.get("hip", {}).get("body_pos_from_fk", True))
     fill_dynamics(cfg.dynamics, cm, env_config, config.get("sim", {}))
