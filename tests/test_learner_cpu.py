@@ -166,3 +166,31 @@ def test_tracking_error_tracker_matches_reference_rule():
     assert torch.allclose(trk._mean, want, atol=1e-5)
     info = trk.test_info()
     assert abs(info["test_mean_dof_vel_tracking_err"] - want[4].item()) < 1e-5 and len(info) == 7
+
+
+def test_td_lambda_against_brute_force_definition():
+    """The reference keeps a brute-force TD(lambda) (the lambda-weighted mixture of n-step returns, truncated at episode
+    ends) beside its recursion but never calls it (rl_util.py:32-74); restated here as the check it was meant to be."""
+    import torch
+    from parc_amd.learning import rl_util
+    g = torch.Generator().manual_seed(4)
+    T, N, disc, lam = 12, 9, 0.97, 0.9
+    r = torch.rand(T, N, generator=g); nv = torch.randn(T, N, generator=g)
+    done = (torch.rand(T, N, generator=g) < 0.2).int() * 2
+    got = rl_util.compute_td_lambda_return(r, nv, done, disc, lam).numpy().astype(np.float64)
+    rr, vv, dd = r.numpy().astype(np.float64), nv.numpy().astype(np.float64), done.numpy()
+    want = np.zeros((T, N))
+    for i in range(N):
+        for t0 in range(T):
+            new_val, sum_r, cd, cl = 0.0, 0.0, 1.0, 1.0
+            for t in range(t0, T):
+                sum_r += cd * rr[t, i]
+                cur = sum_r + cd * disc * vv[t, i]
+                if dd[t, i] == 0 and t < T - 1:
+                    new_val += (1 - lam) * cl * cur
+                else:
+                    new_val += cl * cur
+                    break
+                cd *= disc; cl *= lam
+            want[t0, i] = new_val
+    assert np.abs(got - want).max() < 1e-5
