@@ -12,7 +12,9 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libparc_oracle.so")
+# PARC_ORACLE_LIB selects another build of the same sources (e.g. libparc_oracle_asan.so from `make asan`, run with
+# LD_PRELOAD=$(gcc -print-file-name=libasan.so)): sanitizer runs are CPU-only
+_LIB_PATH = os.environ.get("PARC_ORACLE_LIB", os.path.join(_HERE, "libparc_oracle.so"))
 
 MAXB, MAXD, MAXS, MAXK = 16, 48, 8, 8
 f32p = C.POINTER(C.c_float)
