@@ -477,6 +477,21 @@ class HipParkourEnv(base_env.BaseEnv):
         return
 
     # ---- measurement ------------------------------------------------------------------------------------
+    def set_kernel_timing(self, enable):
+        """hipEvents around the kernels of every step() from now on (no host sync); read with get_kernel_timing()."""
+        L.check(self._lib.parc_env_set_kernel_timing(self._handle, int(bool(enable))))
+
+    def get_kernel_timing(self):
+        """(dynamics ms, obs ms, steps) averaged over the steps since the last call; plus the HBM figures of the obs kernels
+        (HBM_GBps, Roofline_Frac) from the algorithmic 5 772 B per env-step and the 8 TB/s peak."""
+        d, o, n = C.c_double(), C.c_double(), C.c_int32()
+        L.check(self._lib.parc_env_get_kernel_timing(self._handle, C.byref(d), C.byref(o), C.byref(n)))
+        out = {"dynamics_ms": d.value, "obs_ms": o.value, "steps": n.value}
+        if o.value > 0.0:
+            out["hbm_gbps"] = 5772.0 * self._num_envs / (o.value * 1e-3) / 1e9
+            out["roofline_frac"] = out["hbm_gbps"] / 8000.0
+        return out
+
     def profile_step(self, iters=10, action=None):
         a = None if action is None else action.contiguous().data_ptr()
         tot = C.c_float(); post = C.c_float()

@@ -208,7 +208,14 @@ class DMPPOAgent(torch.nn.Module):
         self._exp_buffer.reset()
         self.eval()
         self.set_mode(AgentMode.TRAIN)
+        timed = hasattr(self._env, "set_kernel_timing")
+        if timed:
+            self._env.set_kernel_timing(True)
         self._rollout_train(self._steps_per_iter)
+        kt = None
+        if timed:
+            kt = self._env.get_kernel_timing()
+            self._env.set_kernel_timing(False)
         data_info = self._build_train_data()
         train_info = self._update_model()
         if self._need_normalizer_update():
@@ -219,6 +226,9 @@ class DMPPOAgent(torch.nn.Module):
         info["mean_ep_len"] = self._train_return_tracker.get_mean_ep_len().item()
         info["num_eps"] = self._train_return_tracker.get_episodes()
         info.update(self._train_return_tracker.get_all_mean_returns())
+        if kt is not None and kt["steps"] > 0:  # env kernel time and HBM figures next to the learning curves
+            info["env_dynamics_ms"] = kt["dynamics_ms"]; info["env_obs_ms"] = kt["obs_ms"]
+            info["hbm_gbps"] = kt.get("hbm_gbps", 0.0); info["roofline_frac"] = kt.get("roofline_frac", 0.0)
         return info
 
     def _merge_fail_rates(self):

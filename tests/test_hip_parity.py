@@ -402,6 +402,7 @@ def test_ppo_training_iterations_on_hip_env(tmp_path):
         info = agent._train_iter()
         agent._sample_count = agent._exp_buffer.get_total_samples()
         assert np.isfinite(info["loss"].item()) and np.isfinite(info["critic_loss"].item())
+        assert info["env_dynamics_ms"] > 0.0 and info["env_obs_ms"] > 0.0 and 0.0 < info["roofline_frac"] < 1.0
     assert agent._obs_norm.get_count().item() == 2 * 8 * 512
     assert torch.isfinite(agent._exp_buffer.get_data("obs")).all()
     agent.save(str(tmp_path / "model.pt"))
