@@ -1943,22 +1943,18 @@ extern "C" const char *parc_env_dynamics_kernel(ParcEnv *e) {
     return e->use_wave ? "k_dynamics_wave" : (e->use_coop ? "k_dynamics_coop" : "k_dynamics");
 }
 
-// Diagnostic (-DPARC_STAMPS builds): mean cycles per phase of k_env_post over all envs of the last step.
-extern "C" int parc_env_debug_stamps(ParcEnv *e, double *mean8) {
 #ifdef PARC_STAMPS
+// Diagnostic (-DPARC_STAMPS builds only; the shipped library does not export it): mean cycles per phase of k_env_post
+// over all envs of the last step.
+extern "C" int parc_env_debug_stamps(ParcEnv *e, double *mean8) {
     if (!e || !e->sp.stamp_out) return fail(PARC_ERR_STATE, "no stamp buffer");
     HIPCHK(hipDeviceSynchronize());
     std::vector<unsigned> h((size_t)e->N * 8);
     HIPCHK(hipMemcpy(h.data(), e->sp.stamp_out, h.size() * 4, hipMemcpyDeviceToHost));
     for (int k = 0; k < 8; ++k) { double a = 0; for (int i = 0; i < e->N; ++i) a += h[(size_t)i * 8 + k]; mean8[k] = a / e->N; }
     return PARC_OK;
-#else
-    (void)e; (void)mean8;
-    return fail(PARC_ERR_STATE, "library built without PARC_STAMPS");
-#endif
 }
 
-#ifdef PARC_STAMPS
 // Diagnostic: cycles per phase of k_dynamics_coop summed over all waves since the last call (then cleared).
 extern "C" int parc_env_debug_dyn_stamps(double *out16) {
     unsigned long long h[16], z[16] = {0};
