@@ -29,6 +29,11 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(so, sym), f"{sym} declared in include/parc_env.h but not exported"
     assert declared == set(L.EXPORTED_SYMBOLS)
     assert so.parc_abi_version() == L.ABI_VERSION
+    # and nothing undeclared leaks out of the shipped library
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", L.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("parc_")}
+    assert exported == declared, (exported - declared, declared - exported)
 
 
 def test_struct_layout_matches_c_and_create_fails_loudly_without_gpu():
