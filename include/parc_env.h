@@ -250,6 +250,13 @@ int parc_env_step_reset_graph(ParcEnv *env, void *stream);
 int parc_td_lambda_return(const float *reward, const float *next_vals, const int32_t *done, float discount, float td_lambda,
                           int32_t T, int32_t N, float *ret_out, void *stream);
 
+/* Observation normalisation fused with the experience-buffer write (normalizer.py:87-90 +
+ * experience_buffer.record): one pass reads x [n][dim] and writes  norm = clamp((x - mean) / std, -clip, clip)  and, when
+ * copy_out is not NULL, the unmodified row into the rollout buffer slot.  Same fp32 operations in the same order as the
+ * three torch kernels it replaces (IEEE division), so `norm` is bit-identical to Normalizer.normalize. */
+int parc_normalize_record(const float *x, const float *mean, const float *std, float clip, float *norm_out, float *copy_out,
+                          int64_t n, int32_t dim, void *stream);
+
 /* Recorder (IGParkourEnv.write_agent_states, ig_parkour_env.py:759-796; driven by dm_motion_recorder.py:52-121).
  * The reference appends one row per recording env to Python lists every step; here the rows go to device ring buffers
  * owned by the caller:

@@ -1647,6 +1647,29 @@ extern "C" int parc_td_lambda_return(const float *reward, const float *next_vals
     return PARC_OK;
 }
 
+__global__ __launch_bounds__(256) void k_normalize_record(const float *__restrict__ x, const float *__restrict__ mean, const float *__restrict__ sd,
+                                                          float clip, float *__restrict__ norm_out, float *__restrict__ copy_out, long long total, int dim) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % dim);
+    const float v = x[i];
+    float y = (v - mean[c]) / sd[c];
+    y = fminf(fmaxf(y, -clip), clip);
+    norm_out[i] = y;
+    if (copy_out) copy_out[i] = v;
+}
+
+extern "C" int parc_normalize_record(const float *x, const float *mean, const float *sd, float clip, float *norm_out, float *copy_out,
+                                     int64_t n, int32_t dim, void *stream) {
+    if (!x || !mean || !sd || !norm_out || n < 0 || dim < 1) return fail(PARC_ERR_INVALID, "bad argument");
+    const long long total = (long long)n * dim;
+    if (total == 0) return PARC_OK;
+    hipLaunchKernelGGL(k_normalize_record, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, mean, sd, clip, norm_out,
+                       copy_out, total, dim);
+    HIPCHK(hipGetLastError());
+    return PARC_OK;
+}
+
 // Recorder: one 128-thread block per env appends that env's row (see include/parc_env.h).
 __global__ __launch_bounds__(128) void k_record(const DevTables *__restrict__ T, ParcEnvBuffers buf, int N, int B, int D, int obs_dim, float *frames,
                                                 float *obs_out, int cap, int *count, unsigned char *writing, int *n_writing, int use_ref) {

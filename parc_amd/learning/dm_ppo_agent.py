@@ -240,9 +240,12 @@ class DMPPOAgent(torch.nn.Module):
 
     # ---- rollout (base_agent.py:291-370) --------------------------------------------------------------------
     def _rollout_train(self, num_steps):
+        obs_buf = self._exp_buffer.get_data("obs")
         for _ in range(num_steps):
-            action, action_info = self._decide_action(self._curr_obs, self._curr_info)
-            self._record_data_pre_step(self._curr_obs, self._curr_info, action, action_info)
+            # normalise for the policy and write the raw row into the rollout buffer in one pass over the observation
+            norm_obs = self._obs_norm.normalize_and_record(self._curr_obs, obs_buf[self._exp_buffer.get_buffer_head()])
+            action, action_info = self._decide_action(self._curr_obs, self._curr_info, norm_obs=norm_obs)
+            self._record_data_pre_step(self._curr_obs, self._curr_info, action, action_info, obs_recorded=True)
             next_obs, r, done, next_info = self._step_env(action)
             self._train_return_tracker.update(next_info, done)
             self._record_data_post_step(next_obs, r, done, next_info)
@@ -296,8 +299,9 @@ class DMPPOAgent(torch.nn.Module):
 
     # ---- acting (ppo_agent.py:84-122) -------------------------------------------------------------------------
     @torch.no_grad()
-    def _decide_action(self, obs, info):
-        norm_obs = self._obs_norm.normalize(obs)
+    def _decide_action(self, obs, info, norm_obs=None):
+        if norm_obs is None:
+            norm_obs = self._obs_norm.normalize(obs)
         dist = self._model.eval_actor(norm_obs)
         if self._mode == AgentMode.TRAIN:
             norm_a_rand, norm_a_mode = dist.sample(), dist.mode
@@ -318,8 +322,9 @@ class DMPPOAgent(torch.nn.Module):
             return (1.0 - l) * self._exp_prob_beg + l * self._exp_prob_end
         return self._exp_prob_beg
 
-    def _record_data_pre_step(self, obs, info, action, action_info):
-        self._exp_buffer.record("obs", obs)
+    def _record_data_pre_step(self, obs, info, action, action_info, obs_recorded=False):
+        if not obs_recorded:
+            self._exp_buffer.record("obs", obs)
         self._exp_buffer.record("action", action)
         if self._need_normalizer_update():
             self._obs_norm.record(obs)

@@ -42,6 +42,9 @@ class ExperienceBuffer:
         assert data.shape[0] == self._batch_size
         self._buffers[name][self._buffer_head] = data
 
+    def get_buffer_head(self):
+        return self._buffer_head
+
     def get_data(self, name):
         return self._buffers[name]
 

@@ -89,6 +89,22 @@ class Normalizer(torch.nn.Module):
         norm_x = torch.clamp(norm_x, -self._clip, self._clip)
         return norm_x.type(self.dtype)
 
+    def normalize_and_record(self, x, copy_out=None):
+        """``normalize(x)`` and, in the same pass, ``copy_out[...] = x`` (the rollout buffer slot).  On a GPU this is one
+        kernel of the env library (``parc_normalize_record``, bit-identical to ``normalize``); otherwise the torch ops."""
+        if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2 and
+                (copy_out is None or (copy_out.is_contiguous() and copy_out.shape == x.shape and copy_out.dtype == torch.float32))):
+            if copy_out is not None:
+                copy_out.copy_(x)
+            return self.normalize(x)
+        from parc_amd import lib as L
+        lib = L.load()
+        out = torch.empty_like(x)
+        L.check(lib.parc_normalize_record(x.data_ptr(), self._mean.data_ptr(), self._std.data_ptr(), float(self._clip), out.data_ptr(),
+                                          None if copy_out is None else copy_out.data_ptr(), x.shape[0], x.shape[1],
+                                          torch.cuda.current_stream().cuda_stream))
+        return out
+
     def unnormalize(self, norm_x):
         return (norm_x * self._std + self._mean).type(self.dtype)
 

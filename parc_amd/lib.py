@@ -125,6 +125,7 @@ def load():
     lib.parc_env_get_buffers.argtypes = [vp, C.POINTER(ParcEnvBuffers)]
     lib.parc_env_bind_action.argtypes = [vp, vp]
     lib.parc_env_step_reset_graph.argtypes = [vp, vp]
+    lib.parc_normalize_record.argtypes = [vp, vp, vp, C.c_float, vp, vp, C.c_int64, C.c_int32, vp]
     lib.parc_td_lambda_return.argtypes = [vp, vp, vp, C.c_float, C.c_float, C.c_int32, C.c_int32, vp, vp]
     lib.parc_env_set_episode_length.argtypes = [vp, C.c_float]
     lib.parc_env_record_bind.argtypes = [vp, vp, vp, C.c_int32, vp, vp, vp, C.c_int32]
@@ -145,7 +146,7 @@ EXPORTED_SYMBOLS = [
     "parc_env_reset_with", "parc_env_reset_done", "parc_env_compute_obs", "parc_env_get_fail_rates", "parc_env_set_fail_rates",
     "parc_env_get_motion_info", "parc_env_set_rand_reset", "parc_env_set_start_time_fraction", "parc_dof_to_rot",
     "parc_rot_to_dof", "parc_forward_kinematics", "parc_calc_motion_frame", "parc_env_get_frame_vel_tables",
-    "parc_env_profile_step", "parc_env_last_dynamics_ms", "parc_env_dynamics_kernel", "parc_env_set_kernel_timing", "parc_env_get_kernel_timing", "parc_env_record_bind", "parc_env_record_frame", "parc_env_set_episode_length", "parc_td_lambda_return", "parc_env_bind_action", "parc_env_get_buffers", "parc_env_step_reset_graph",
+    "parc_env_profile_step", "parc_env_last_dynamics_ms", "parc_env_dynamics_kernel", "parc_env_set_kernel_timing", "parc_env_get_kernel_timing", "parc_env_record_bind", "parc_env_record_frame", "parc_env_set_episode_length", "parc_td_lambda_return", "parc_normalize_record", "parc_env_bind_action", "parc_env_get_buffers", "parc_env_step_reset_graph",
 ]
 
 

@@ -629,3 +629,21 @@ def test_graph_step_equals_step_plus_reset_done(tmp_path, dyn):
     total_done = int(a._ep_num_buf.sum().item()) - n   # every reset bumps ep_num; the first one was reset()
     assert total_done > 500, total_done
     assert np.array_equal(a.get_fail_rates().numpy(), b.get_fail_rates().numpy())
+
+
+def test_fused_normalize_record_bit_exact():
+    """parc_normalize_record == Normalizer.normalize (normalizer.py:87-90) bit for bit, and copies the raw rows."""
+    import torch
+    from parc_amd.learning.normalizer import Normalizer
+    g = torch.Generator().manual_seed(2)
+    n, dim = 3001, 1312
+    nz = Normalizer((dim,), "cuda:0", clip=10.0)
+    mean = torch.randn(dim, generator=g).cuda() * 3.0
+    std = (torch.rand(dim, generator=g).cuda() * 2.0 + 0.01)
+    nz.set_mean_std(mean, std)
+    x = (torch.randn(n, dim, generator=g) * 20.0).cuda()
+    slot = torch.zeros_like(x)
+    got = nz.normalize_and_record(x, slot)
+    want = nz.normalize(x)
+    assert torch.equal(got, want) and torch.equal(slot, x)
+    assert (want.abs().max() <= nz._clip) and (want.abs() == nz._clip).any()   # the clamp is exercised
