@@ -189,3 +189,29 @@ def test_ray_division_shortcut_is_exact():
         lo, hi = (2.0 ** -7, 2.0 ** 13) if d == 0.4 else (2.0 ** -3, 2.0 ** 9)
         n = lib.parc_check_rcp_division(np.float32(d), lo, hi, C.byref(bad_x))
         assert n == 0, (d, n, bad_x.value)
+
+
+def test_create_dataset_yaml_class_balanced_weights(tmp_path):
+    """util/create_dataset.py:20-177: weight = length x factor with equal total mass per first-level folder; the YAML loads
+    back through the motion-file loader."""
+    import shutil
+    import yaml
+    from parc_amd import motion_lib
+    from parc_amd.util.create_dataset import create_dataset_yaml
+    root = tmp_path / "ds"
+    for cls, clips in {"walk": ["civilization", "sfu"], "parkour": ["TEASER_TERRAIN"], "ignore_me": ["sfu"]}.items():
+        (root / cls / "batch0").mkdir(parents=True)
+        for c in clips:
+            shutil.copy(os.path.join(DATA, "motion_terrains", c + ".pkl"), root / cls / "batch0" / (c + "_" + cls + ".pkl"))
+    out = create_dataset_yaml([root], tmp_path / "ds.yaml", verbose=False)
+    y = yaml.safe_load(open(tmp_path / "ds.yaml"))
+    assert len(y["motions"]) == 3 and not any("ignore" in m["file"] for m in y["motions"])
+    mass = {}
+    for m in y["motions"]:
+        cls = "walk" if "/walk/" in m["file"] else "parkour"
+        mass[cls] = mass.get(cls, 0.0) + m["weight"]
+    assert abs(mass["walk"] - mass["parkour"]) < 1e-9 * max(mass.values())
+    w = {os.path.basename(m["file"]): m["weight"] for m in y["motions"]}
+    assert abs(w["civilization_walk.pkl"] / w["sfu_walk.pkl"] - (254 / 30) / (15 / 30)) < 1e-9   # within a class: proportional to length
+    clips = motion_lib.load_motion_file(str(tmp_path / "ds.yaml"), verbose=False)
+    assert [c.name for c in clips] == [os.path.splitext(os.path.basename(m["file"]))[0] for m in y["motions"]]
