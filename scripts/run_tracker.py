@@ -81,6 +81,9 @@ def run(args):
         Logger.print("Mean Return: {}".format(result["mean_return"]))
         Logger.print("Mean Episode Length: {}".format(result["mean_ep_len"]))
         Logger.print("Episodes: {}".format(result["num_eps"]))
+        for key in result:  # run_tracker.py:54-56: the tracking-error means when the env reports them
+            if "test_mean" in key:
+                Logger.print(key + ": {}".format(result[key]))
     elif mode == "record":  # PARC stage 4 (parc_4_phys_record.py -> run_tracker.run mode record -> record_dm_motions)
         from parc_amd.learning.dm_motion_recorder import record_dm_motions
         record_dm_motions(agent)
