@@ -29,7 +29,8 @@ namespace parcdyn {
 #define WV_MAXLIMB 4  // limb chains = waves per block
 #define WV_MAXATT 3   // trunk bodies that carry limbs
 #define WV_PI (DYN_PATCH - 4)
-#define WV_FAC 21     // K (18) + D^-1 u (3)
+#define WV_P3 (DYN_PATCH - 2)  // cells that have a full 3x3 neighbourhood inside the patch
+#define WV_FAC 21     // K (18) + D^-1 u (3); a hinge uses slots 0..5 (K) and 6 (D^-1 u)
 
 struct WaveTables {
     int nlimb;
@@ -43,6 +44,8 @@ struct WaveTables {
     int child[WV_MAXLEN][WV_MAXLIMB];      // limb chain ids (1..)
     int npt[DYN_MAXB], pt0[DYN_MAXB];
     float brad[DYN_MAXB];
+    int fac_off[1 + WV_MAXLIMB][WV_MAXLEN]; // first LDS slot of a body's joint-space factors (spherical 21, hinge 7, fixed / root 0)
+    int fac_total;                          // slots in use (humanoid: 196)
 };
 
 // LDS layout (floats); everything is [slot][64 lanes]
@@ -52,9 +55,11 @@ struct WaveTables {
 #define WV_OFF_ROOTP (WV_OFF_ATTACC + WV_MAXATT * 6 * 64)
 #define WV_OFF_PATCH (WV_OFF_ROOTP + 3 * 64)
 #define WV_OFF_PMAX (WV_OFF_PATCH + DYN_PATCH * DYN_PATCH * 64)
-#define WV_OFF_FAC (WV_OFF_PMAX + WV_PI * WV_PI * 64)
-#define WV_OFF_ROOTI (WV_OFF_FAC + (1 + WV_MAXLIMB) * WV_MAXLEN * WV_FAC * 64)
-#define WV_LDS_FLOATS (WV_OFF_ROOTI + 30 * 64)
+#define WV_OFF_PMAX3 (WV_OFF_PMAX + WV_PI * WV_PI * 64)
+#define WV_OFF_ROOTI (WV_OFF_PMAX3 + WV_P3 * WV_P3 * 64)
+#define WV_OFF_FAC (WV_OFF_ROOTI + 30 * 64)
+#define WV_LDS_FLOATS_MAX (WV_OFF_FAC + (1 + WV_MAXLIMB) * WV_MAXLEN * WV_FAC * 64)
+inline int wv_lds_floats(int fac_total) { return WV_OFF_FAC + fac_total * 64; } // the factor region is last and packed
 
 inline bool build_wave_tables(const DynModel &M, const CoopTables &C, WaveTables &W) {
     memset(&W, 0, sizeof(W));
@@ -79,10 +84,35 @@ inline bool build_wave_tables(const DynModel &M, const CoopTables &C, WaveTables
     for (int b = 0; b < M.B; ++b) { W.npt[b] = C.npt[b]; W.pt0[b] = C.pt0[b]; W.brad[b] = C.brad[b]; }
     W.helper = -1;
     for (int c = 2; c < C.nchain; ++c) if (W.early[c] && W.att_slot[0] >= 0) { W.helper = c - 1; break; }
+    int off = 0;
+    for (int c = 0; c < C.nchain; ++c)
+        for (int k = 0; k < W.len[c]; ++k) {
+            const int b = W.body[c][k], jt = M.jtype[b];
+            W.fac_off[c][k] = off;
+            off += (b == 0) ? 0 : (jt == DJ_SPHERICAL ? WV_FAC : (jt == DJ_HINGE ? 7 : 0));
+        }
+    W.fac_total = off;
+    if (wv_lds_floats(off) * (int)sizeof(float) > 160 * 1024) return false; // does not fit one CU's LDS: the caller falls back to the chain-parallel kernel
     return true;
 }
 
 #if defined(__HIPCC__)
+
+// Diagnostic builds only (-DPARC_STAMPS): cycles between consecutive stamp points, summed per wave role over all blocks.
+// Even slots = work segments, odd slots = the barrier wait that follows (see the WSTAMP calls in the substep loop).
+#ifdef PARC_STAMPS
+__device__ unsigned long long g_wave_stamps[4][16];
+#define WSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); wacc[i] += t_ - wlast; wlast = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+// pin: the 27 values of (IA, pA) must be complete before the stamp that follows (keeps arithmetic from sinking past it)
+#define WPIN(IA_, pA_) do { for (int i_ = 0; i_ < 21; ++i_) asm volatile("" : "+v"((IA_).s[i_])); for (int i_ = 0; i_ < 6; ++i_) asm volatile("" : "+v"((pA_).a[i_])); } while (0)
+#define WSTAMP_PARAMS , unsigned long long *wacc, unsigned long long &wlast
+#define WSTAMP_ARGS , wacc, wlast
+#else
+#define WSTAMP(i) do { } while (0)
+#define WPIN(IA_, pA_) do { } while (0)
+#define WSTAMP_PARAMS
+#define WSTAMP_ARGS
+#endif
 
 struct WvBody { // per-body registers of the owning lane
     q4 jq, tq; float hang, thang; v3 qd; // joint state (spherical: quaternion + child-frame omega; hinge: angle + rate)
@@ -127,14 +157,53 @@ __device__ __forceinline__ void wv_fk_body(const DynModel &M, int b, WvBody &B, 
 }
 
 struct WvCtx { // per-lane constants of the control step
-    const float *s_patch, *s_pmax; // + lane
+    const float *s_patch, *s_pmax, *s_pmax3; // + lane
     int pox, poy;
     float eo0, eo1, eo2, cell_min, dt;
 };
 
+// One contact (point at x relative to O, velocity vpt, penetration pen along the unit normal n): explicit force into pA,
+// implicit term dt X^T (beta 1 + (bn - beta) n n^T) X into IA (parc_dynamics.hpp, dyn_control_step, "contacts").
+__device__ __forceinline__ void wv_contact_generic(const DynModel &M, float dt, v3 x, v3 vpt, float pen, v3 n, sym6 &IA, s6 &pA, v3 &fsum) {
+    const float vn = dot(vpt, n);
+    float fn = M.kn * pen - M.dn * vn;
+    if (fn < 0.f) fn = 0.f;
+    const v3 vt = vpt - vn * n;
+    const float vtm = DYN_SQRT(dot(vt, vt));
+    float beta = M.dtang;
+    if (beta * vtm > M.mu * fn) beta = vtm > 1e-9f ? M.mu * fn * DYN_RCP(vtm) : 0.f;
+    const v3 f = fn * n - beta * vt;
+    const v3 no = cross(x, f);
+    pA.a[0] -= no.x; pA.a[1] -= no.y; pA.a[2] -= no.z; pA.a[3] -= f.x; pA.a[4] -= f.y; pA.a[5] -= f.z;
+    fsum = fsum + f;
+    const float bn = fn > 0.f ? (M.dn + dt * M.kn) : 0.f;
+    add_inertia(IA, dt * beta, x, nullptr);
+    symrank1(IA, dt * (bn - beta), s6mk(cross(x, n), n));
+}
+
+// The same for the column of the sphere's OWN cell, where the normal is +z by construction: sphere_vs_column's two
+// branches both give n = (0,0,1), pen = rad + top - z for a centre that lies inside the cell's footprint.  The rank-1
+// term then has three non-zero components, w = (x.y, -x.x, 0, 0, 0, 1): 6 entries of IA instead of 21.
+__device__ __forceinline__ void wv_contact_own(const DynModel &M, float dt, v3 x, v3 vpt, float pen, sym6 &IA, s6 &pA, v3 &fsum) {
+    float fn = M.kn * pen - M.dn * vpt.z;
+    if (fn < 0.f) fn = 0.f;
+    const float vtm = DYN_SQRT(vpt.x * vpt.x + vpt.y * vpt.y);
+    float beta = M.dtang;
+    if (beta * vtm > M.mu * fn) beta = vtm > 1e-9f ? M.mu * fn * DYN_RCP(vtm) : 0.f;
+    const v3 f = mk(-beta * vpt.x, -beta * vpt.y, fn);
+    const v3 no = cross(x, f);
+    pA.a[0] -= no.x; pA.a[1] -= no.y; pA.a[2] -= no.z; pA.a[3] -= f.x; pA.a[4] -= f.y; pA.a[5] -= f.z;
+    fsum = fsum + f;
+    const float bn = fn > 0.f ? (M.dn + dt * M.kn) : 0.f;
+    add_inertia(IA, dt * beta, x, nullptr);
+    const float k = dt * (bn - beta);
+    IA.s[sidx(0, 0)] += k * x.y * x.y; IA.s[sidx(0, 1)] -= k * x.y * x.x; IA.s[sidx(0, 5)] += k * x.y;
+    IA.s[sidx(1, 1)] += k * x.x * x.x; IA.s[sidx(1, 5)] -= k * x.x; IA.s[sidx(5, 5)] += k;
+}
+
 // articulated inertia / bias of body b: own inertia + contacts + (IA, pA) carried in from the chain's child
 __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTables &W, const DynTerrain &T, const WvCtx &X, int b, WvBody &B,
-                                                const m3 &R, v3 rootp, sym6 &IA, s6 &pA) {
+                                                const m3 &R, v3 rootp, sym6 &IA, s6 &pA WSTAMP_PARAMS) {
     const v3 r = B.r;
     const float dt = X.dt;
     {
@@ -166,6 +235,8 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
         pA.a[0] += pb.a[0] - ng.x; pA.a[1] += pb.a[1] - ng.y; pA.a[2] += pb.a[2] - ng.z;
         pA.a[3] += pb.a[3] - fg.x; pA.a[4] += pb.a[4] - fg.y; pA.a[5] += pb.a[5] - fg.z;
     }
+    WPIN(IA, pA);
+    WSTAMP(12);
     // contacts.  A body whose bounding sphere clears every column its collision spheres could touch is skipped
     // (exact: those contributions are zero).
     v3 fsum = mk(0.f, 0.f, 0.f);
@@ -179,53 +250,69 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
             if (r.z + rootp.z + X.eo2 - brad > hmax) near = false;
         }
     }
+#ifdef WV_EXP_NOCONTACT
+    near = false;
+#endif
     if (near) {
+        // Narrow phase.  A sphere can only touch the column of its own cell and the columns of the neighbours on the sides
+        // whose face is closer than its radius (for rad < half a cell: at most the x-side, the y-side and their diagonal;
+        // the far sides are at least half a cell away).  Everything is culled with ONE look-up of the 3x3 running maximum
+        // around the sphere's cell; the decision whether a candidate is a contact stays with sphere_vs_column / the
+        // penetration sign, so the result equals the exhaustive 9-column test of parc_dynamics.hpp.
         const int npt = W.npt[b], pt0 = W.pt0[b];
+        const float hx = 0.5f * T.dx, hy = 0.5f * T.dy;
         for (int pi = 0; pi < npt; ++pi) {
             const int kp = pt0 + pi;
             const v3 x = r + mulv(R, mk(M.col_pos[kp][0], M.col_pos[kp][1], M.col_pos[kp][2]));
             const v3 g = mk(x.x + rootp.x + X.eo0, x.y + rootp.y + X.eo1, x.z + rootp.z + X.eo2);
             const float rad = M.col_r[kp];
-            if (g.z - rad > hmax) continue; // e.g. the upper corners of a foot that stands on the ground
+            const float zlo = g.z - rad;
+            if (zlo > hmax) continue; // e.g. the upper corners of a foot that stands on the ground
             const int ix = cell_of(g.x, T.min_x, T.dx), iy = cell_of(g.y, T.min_y, T.dy);
             const int pa_ = ix - X.pox, pb_ = iy - X.poy;
             const bool inp = pa_ >= 1 && pa_ < DYN_PATCH - 1 && pb_ >= 1 && pb_ < DYN_PATCH - 1;
-            const float top0 = inp ? X.s_patch[(pa_ * DYN_PATCH + pb_) * 64] : hf_at(T, ix, iy);
-            // candidate columns of this sphere: its own cell, and neighbours that stand higher (walls / edges); one bit each
-            unsigned cand = 0u;
-            PARC_UNROLL
-            for (int nb = 0; nb < 9; ++nb) {
-                const int ox_ = (nb % 3) - 1, oy_ = (nb / 3) - 1;
-                const float top = nb == 4 ? top0 : (inp ? X.s_patch[((pa_ + ox_) * DYN_PATCH + pb_ + oy_) * 64] : hf_at(T, ix + ox_, iy + oy_));
-                if ((nb == 4 || top > top0 + 1e-3f) && !(g.z - rad > top)) cand |= 1u << nb;
+            if (inp && rad + 2e-3f < X.cell_min * 0.5f) {
+                if (zlo > X.s_pmax3[((pa_ - 1) * WV_P3 + pb_ - 1) * 64]) continue; // above every column it could reach
+                const float top0 = X.s_patch[(pa_ * DYN_PATCH + pb_) * 64];
+                const v3 vpt = s6lin(B.vel) + cross(s6ang(B.vel), x);
+                const float pen0 = rad + top0 - g.z;
+                if (pen0 > 0.f) wv_contact_own(M, dt, x, vpt, pen0, IA, pA, fsum);
+                const float ex = g.x - (T.min_x + (float)ix * T.dx), ey = g.y - (T.min_y + (float)iy * T.dy);
+                const float lim = rad + 1e-3f; // slack >> the rounding of the cell centres: it only admits candidates
+                const bool nx = hx - fabsf(ex) < lim, ny = hy - fabsf(ey) < lim;
+                if (nx || ny) {
+                    const int sx = ex >= 0.f ? 1 : -1, sy = ey >= 0.f ? 1 : -1;
+                    for (int c = 0; c < 3; ++c) { // x side, y side, diagonal
+                        const bool want = c == 0 ? nx : (c == 1 ? ny : (nx && ny));
+                        if (!want) continue;
+                        const int ox_ = c == 1 ? 0 : sx, oy_ = c == 0 ? 0 : sy;
+                        const float top = X.s_patch[((pa_ + ox_) * DYN_PATCH + pb_ + oy_) * 64];
+                        if (!(top > top0 + 1e-3f) || zlo > top) continue; // only higher neighbours act as walls / step edges
+                        v3 n;
+                        const float pen = sphere_vs_column(T, g, rad, ix + ox_, iy + oy_, top, n);
+                        if (pen > 0.f) wv_contact_generic(M, dt, x, vpt, pen, n, IA, pA, fsum);
+                    }
+                }
             }
-            if (cand == 0u) continue;
-            const v3 vpt = s6lin(B.vel) + cross(s6ang(B.vel), x);
-            for (int nb = 0; nb < 9; ++nb) {
-                if (!((cand >> nb) & 1u)) continue;
-                const int ox_ = (nb % 3) - 1, oy_ = (nb / 3) - 1;
-                const float top = nb == 4 ? top0 : (inp ? X.s_patch[((pa_ + ox_) * DYN_PATCH + pb_ + oy_) * 64] : hf_at(T, ix + ox_, iy + oy_));
-                v3 n;
-                const float pen = sphere_vs_column(T, g, rad, ix + ox_, iy + oy_, top, n);
-                if (!(pen > 0.f)) continue;
-                const float vn = dot(vpt, n);
-                float fn = M.kn * pen - M.dn * vn;
-                if (fn < 0.f) fn = 0.f;
-                const v3 vt = vpt - vn * n;
-                const float vtm = DYN_SQRT(dot(vt, vt));
-                float beta = M.dtang;
-                if (beta * vtm > M.mu * fn) beta = vtm > 1e-9f ? M.mu * fn * DYN_RCP(vtm) : 0.f;
-                const v3 f = fn * n - beta * vt;
-                const v3 no = cross(x, f);
-                pA.a[0] -= no.x; pA.a[1] -= no.y; pA.a[2] -= no.z; pA.a[3] -= f.x; pA.a[4] -= f.y; pA.a[5] -= f.z;
-                fsum = fsum + f;
-                const float bn = fn > 0.f ? (M.dn + dt * M.kn) : 0.f;
-                add_inertia(IA, dt * beta, x, nullptr);
-                symrank1(IA, dt * (bn - beta), s6mk(cross(x, n), n));
+#ifndef WV_EXP_NOSLOW
+            else { // outside the staged patch (or a sphere wider than a cell): exhaustive test, heights from global memory
+                const float top0 = inp ? X.s_patch[(pa_ * DYN_PATCH + pb_) * 64] : hf_at(T, ix, iy);
+                const v3 vpt = s6lin(B.vel) + cross(s6ang(B.vel), x);
+                for (int nb = 0; nb < 9; ++nb) {
+                    const int ox_ = (nb % 3) - 1, oy_ = (nb / 3) - 1;
+                    const float top = nb == 4 ? top0 : (inp ? X.s_patch[((pa_ + ox_) * DYN_PATCH + pb_ + oy_) * 64] : hf_at(T, ix + ox_, iy + oy_));
+                    if (!(nb == 4 || top > top0 + 1e-3f) || zlo > top) continue;
+                    v3 n;
+                    const float pen = sphere_vs_column(T, g, rad, ix + ox_, iy + oy_, top, n);
+                    if (pen > 0.f) wv_contact_generic(M, dt, x, vpt, pen, n, IA, pA, fsum);
+                }
             }
+#endif
         }
     }
     B.fcon = fsum;
+    WPIN(IA, pA);
+    WSTAMP(13);
 }
 
 // joint elimination of body b: (IA, pA) -> contribution (Ic, pc) to the parent; K and D^-1 u go to LDS (fac + lane, stride 64)
@@ -326,7 +413,7 @@ __device__ __forceinline__ void wv_joint_inward(const DynModel &M, int b, const 
         const s6 Iac = symmul(Ic, B.cJ);
         PARC_UNROLL
         for (int q = 0; q < 6; ++q) { pc.a[q] = pA.a[q] + Iac.a[q] + Kc.a[q] * uu; fac[q * 64] = Kc.a[q]; }
-        fac[18 * 64] = di_ * uu;
+        fac[6 * 64] = di_ * uu;
     } else { // fixed joint
         const s6 Iac = symmul(IA, B.cJ);
         Ic = IA;
@@ -354,7 +441,7 @@ __device__ __forceinline__ void wv_joint_outward(const DynModel &M, int b, WvBod
         float ka = 0.f;
         PARC_UNROLL
         for (int a = 0; a < 6; ++a) ka += fac[a * 64] * ai.a[a];
-        const float qa = fac[18 * 64] - ka;
+        const float qa = fac[6 * 64] - ka;
         B.qdd = mk(qa, 0.f, 0.f);
         const v3 wj = qa * mulv(qmat(B.bq), mk(M.axis[b][0], M.axis[b][1], M.axis[b][2]));
         ai = ai + s6mk(wj, cross(B.r, wj));
@@ -399,12 +486,15 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
     const float dt = M.dt;
     const int B_ = M.B, D_ = M.D, nsub = M.nsub;
     const int lc = w + 1;              // this wave's limb chain
+#ifdef PARC_STAMPS
+    unsigned long long wacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, wlast = __builtin_readcyclecounter();
+#endif
     const bool has_limb = w < W.nlimb;
     const int llen = has_limb ? W.len[lc] : 0, tlen = w == 0 ? W.len[0] : 0;
 
     float *s_attkin = smem + WV_OFF_ATTKIN + lane, *s_up = smem + WV_OFF_UP + lane, *s_attacc = smem + WV_OFF_ATTACC + lane;
     float *s_rootp = smem + WV_OFF_ROOTP + lane, *s_patch = smem + WV_OFF_PATCH + lane, *s_pmax = smem + WV_OFF_PMAX + lane;
-    float *s_fac = smem + WV_OFF_FAC + lane, *s_rooti = smem + WV_OFF_ROOTI + lane;
+    float *s_fac = smem + WV_OFF_FAC + lane, *s_rooti = smem + WV_OFF_ROOTI + lane, *s_pmax3 = smem + WV_OFF_PMAX3 + lane;
 
     const float *dp = buf.char_dof_pos + (size_t)D_ * ec, *dv = buf.char_dof_vel + (size_t)D_ * ec, *ac = action + (size_t)D_ * ec;
     WvBody limb[WV_MAXLEN], trunk[WV_MAXLEN];
@@ -420,21 +510,33 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
     v3 rw = mk(buf.char_root_ang_vel[3 * ec], buf.char_root_ang_vel[3 * ec + 1], buf.char_root_ang_vel[3 * ec + 2]);
 
     WvCtx X;
-    X.s_patch = s_patch; X.s_pmax = s_pmax; X.dt = dt;
+    X.s_patch = s_patch; X.s_pmax = s_pmax; X.s_pmax3 = s_pmax3; X.dt = dt;
     X.eo0 = env_off_all[3 * ec]; X.eo1 = env_off_all[3 * ec + 1]; X.eo2 = env_off_all[3 * ec + 2];
     X.cell_min = fminf(T.dx, T.dy);
     X.pox = cell_of(rp.x + X.eo0, T.min_x, T.dx) - DYN_PATCH / 2; X.poy = cell_of(rp.y + X.eo1, T.min_y, T.dy) - DYN_PATCH / 2;
-    // local height patch of each env (the 4 waves share the 81 cells), then its 5x5 running maximum
+    // local height patch of each env (the 4 waves share the 81 cells), then its 3x3 and 5x5 running maxima
     for (int i = w; i < DYN_PATCH * DYN_PATCH; i += 4) s_patch[i * 64] = hf_at(T, X.pox + i / DYN_PATCH, X.poy + i % DYN_PATCH);
     __syncthreads();
-    for (int i = w; i < WV_PI * WV_PI; i += 4) {
-        const int pi_ = i / WV_PI + 2, pj_ = i % WV_PI + 2;
+    for (int i = w; i < WV_P3 * WV_P3; i += 4) {
+        const int pi_ = i / WV_P3 + 1, pj_ = i % WV_P3 + 1;
         float m = -3.0e38f;
-        for (int a = -2; a <= 2; ++a) for (int q = -2; q <= 2; ++q) m = fmaxf(m, s_patch[((pi_ + a) * DYN_PATCH + pj_ + q) * 64]);
+        PARC_UNROLL
+        for (int a = -1; a <= 1; ++a) {
+            PARC_UNROLL
+            for (int q = -1; q <= 1; ++q) m = fmaxf(m, s_patch[((pi_ + a) * DYN_PATCH + pj_ + q) * 64]);
+        }
+        s_pmax3[i * 64] = m;
+    }
+    __syncthreads();
+    for (int i = w; i < WV_PI * WV_PI; i += 4) { // 5x5 window = the four 3x3 windows at the diagonal offsets
+        const int pi_ = i / WV_PI + 1, pj_ = i % WV_PI + 1; // centre (pi_+1, pj_+1) in patch cells = (pi_, pj_) in the 3x3 table
+        const float m = fmaxf(fmaxf(s_pmax3[((pi_ - 1) * WV_P3 + pj_ - 1) * 64], s_pmax3[((pi_ - 1) * WV_P3 + pj_ + 1) * 64]),
+                              fmaxf(s_pmax3[((pi_ + 1) * WV_P3 + pj_ - 1) * 64], s_pmax3[((pi_ + 1) * WV_P3 + pj_ + 1) * 64]));
         s_pmax[i * 64] = m;
     }
     __syncthreads();
 
+    WSTAMP(0); // prologue: state load, height patch, running max
     for (int sub = 0; sub < nsub; ++sub) {
         // ---- phase 1: trunk kinematics (wave 0) -------------------------------------------------------------------------
         if (w == 0) {
@@ -454,7 +556,9 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
                 }
             }
         }
+        WSTAMP(1);
         __syncthreads();
+        WSTAMP(2);
         const v3 rootp = mk(s_rootp[0], s_rootp[64], s_rootp[128]);
         // ---- phase 2: inward pass.  Limbs that hang off the upper trunk ("early": the arms) run completely in part A;
         // limbs that hang off the root body ("late": the legs) do their tip body there (the foot, usually the one with
@@ -468,8 +572,11 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
             const int b = W.body[lc][k];
             const m3 R = qmat(limb[k].bq);
             sym6 IA = Icl; s6 pA = pcl;
-            wv_body_inertia(M, W, T, X, b, limb[k], R, rootp, IA, pA);
-            wv_joint_inward(M, b, limb[k], R, dt, IA, pA, Icl, pcl, s_fac + (lc * WV_MAXLEN + k) * WV_FAC * 64);
+            WSTAMP(15);
+            wv_body_inertia(M, W, T, X, b, limb[k], R, rootp, IA, pA WSTAMP_ARGS);
+            wv_joint_inward(M, b, limb[k], R, dt, IA, pA, Icl, pcl, s_fac + W.fac_off[lc][k] * 64);
+            WPIN(Icl, pcl);
+            WSTAMP(14);
         };
         auto limb_handover = [&]() __attribute__((always_inline)) {
             float *u = s_up + (lc - 1) * 27 * 64;
@@ -487,12 +594,15 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
             for (int a = 0; a < 6; ++a) pv.a[a] = s[(7 + a) * 64];
             PARC_UNROLL
             for (int k = 0; k < WV_MAXLEN; ++k) if (k < llen) wv_fk_body(M, W.body[lc][k], limb[k], pq, pr, pv);
+            WSTAMP(11);
             PARC_UNROLL
             for (int k = WV_MAXLEN - 1; k >= 0; --k)
                 if (k < llen && (early || k == llen - 1)) limb_body(k);
             if (early || llen == 1) limb_handover();
         }
+        WSTAMP(3);
         __syncthreads();
+        WSTAMP(4);
         sym6 Ict; s6 pct = s6zero();   // carry of the trunk
         PARC_UNROLL
         for (int i = 0; i < 21; ++i) Ict.s[i] = 0.f;
@@ -508,7 +618,8 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
                 for (int a = 0; a < 6; ++a) pA.a[a] += s_rooti[(21 + a) * 64];
                 trunk[k].fcon = mk(s_rooti[27 * 64], s_rooti[28 * 64], s_rooti[29 * 64]);
             } else {
-                wv_body_inertia(M, W, T, X, b, trunk[k], R, rootp, IA, pA);
+                WSTAMP(15);
+                wv_body_inertia(M, W, T, X, b, trunk[k], R, rootp, IA, pA WSTAMP_ARGS);
             }
             for (int ci = 0; ci < W.nchild[k]; ++ci) {
                 const float *u = s_up + (W.child[k][ci] - 1) * 27 * 64;
@@ -554,7 +665,7 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
                 PARC_UNROLL
                 for (int a = 0; a < 6; ++a) acc_root.a[a] = xs[a];
             } else {
-                wv_joint_inward(M, b, trunk[k], R, dt, IA, pA, Ict, pct, s_fac + k * WV_FAC * 64);
+                wv_joint_inward(M, b, trunk[k], R, dt, IA, pA, Ict, pct, s_fac + W.fac_off[0][k] * 64);
             }
         };
         if (w == 0) { // part B, trunk: every body but the root
@@ -571,7 +682,8 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
             sym6 IA; s6 pA = s6zero();
             PARC_UNROLL
             for (int i = 0; i < 21; ++i) IA.s[i] = 0.f;
-            wv_body_inertia(M, W, T, X, W.body[0][0], rb, qmat(rb.bq), rootp, IA, pA);
+            WSTAMP(15);
+            wv_body_inertia(M, W, T, X, W.body[0][0], rb, qmat(rb.bq), rootp, IA, pA WSTAMP_ARGS);
             PARC_UNROLL
             for (int i = 0; i < 21; ++i) s_rooti[i * 64] = IA.s[i];
             PARC_UNROLL
@@ -583,7 +695,9 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
             for (int k = WV_MAXLEN - 2; k >= 0; --k) if (k < llen - 1) limb_body(k);
             limb_handover();
         }
+        WSTAMP(5);
         __syncthreads();
+        WSTAMP(6);
         // ---- phase 3: root body, floating-base solve, trunk outward, trunk/root integration (wave 0) ------------------
         if (w == 0) {
             trunk_body(0);
@@ -592,7 +706,7 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
             for (int k = 0; k < WV_MAXLEN; ++k) {
                 if (k < tlen) {
                     const int b = W.body[0][k];
-                    if (b != 0) wv_joint_outward(M, b, trunk[k], ap, s_fac + k * WV_FAC * 64);
+                    if (b != 0) wv_joint_outward(M, b, trunk[k], ap, s_fac + W.fac_off[0][k] * 64);
                     const int slot = W.att_slot[k];
                     if (slot >= 0) {
                         PARC_UNROLL
@@ -615,7 +729,9 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
             PARC_UNROLL
             for (int k = 0; k < WV_MAXLEN; ++k) if (k < tlen) wv_integrate_joint(M, W.body[0][k], trunk[k], dt);
         }
+        WSTAMP(7);
         __syncthreads();
+        WSTAMP(8);
         // ---- phase 4: limb outward pass + integration (all waves) -------------------------------------------------------
         if (has_limb) {
             s6 ap;
@@ -625,11 +741,12 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
             for (int k = 0; k < WV_MAXLEN; ++k) {
                 if (k < llen) {
                     const int b = W.body[lc][k];
-                    wv_joint_outward(M, b, limb[k], ap, s_fac + (lc * WV_MAXLEN + k) * WV_FAC * 64);
+                    wv_joint_outward(M, b, limb[k], ap, s_fac + W.fac_off[lc][k] * 64);
                     wv_integrate_joint(M, b, limb[k], dt);
                 }
             }
         }
+        WSTAMP(9);
     }
     // ---- write back -----------------------------------------------------------------------------------------------------
     if (!env_ok) return;
@@ -645,6 +762,10 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
         if (k < llen) wv_store_joint(M, W.body[lc][k], limb[k], odp, odv, ocf);
         if (k < tlen) wv_store_joint(M, W.body[0][k], trunk[k], odp, odv, ocf);
     }
+#ifdef PARC_STAMPS
+    WSTAMP(10);
+    if (lane == 0) for (int i = 0; i < 16; ++i) atomicAdd(&g_wave_stamps[w][i], wacc[i]);
+#endif
 }
 #endif // __HIPCC__
 

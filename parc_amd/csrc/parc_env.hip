@@ -1381,7 +1381,7 @@ extern "C" int parc_env_create(const ParcEnvConfig *cfg, ParcEnv **out) {
         if (e->use_wave) {
             r = up((void **)&e->d_wave, &e->h_wave, sizeof(e->h_wave));
             if (r == hipSuccess)
-                r = hipFuncSetAttribute((const void *)parcdyn::k_dynamics_wave, hipFuncAttributeMaxDynamicSharedMemorySize, WV_LDS_FLOATS * (int)sizeof(float));
+                r = hipFuncSetAttribute((const void *)parcdyn::k_dynamics_wave, hipFuncAttributeMaxDynamicSharedMemorySize, parcdyn::wv_lds_floats(e->h_wave.fac_total) * (int)sizeof(float));
         } else if (e->use_coop) {
             r = up((void **)&e->d_coop, &e->h_coop, sizeof(e->h_coop));
         }
@@ -1551,7 +1551,7 @@ static int launch_dynamics(ParcEnv *e, const float *action_dev, hipStream_t st) 
     parcdyn::DynTerrain T;
     T.hf = e->d_hf; T.X = e->sp.X; T.Y = e->sp.Y; T.min_x = e->sp.min_x; T.min_y = e->sp.min_y; T.dx = e->sp.dx; T.dy = e->sp.dy;
     if (e->use_wave)
-        hipLaunchKernelGGL(parcdyn::k_dynamics_wave, dim3((e->N + 63) / 64), dim3(256), WV_LDS_FLOATS * sizeof(float), st,
+        hipLaunchKernelGGL(parcdyn::k_dynamics_wave, dim3((e->N + 63) / 64), dim3(256), parcdyn::wv_lds_floats(e->h_wave.fac_total) * sizeof(float), st,
                            (const parcdyn::DynModel *)e->d_dyn, (const parcdyn::WaveTables *)e->d_wave, T, e->sp.buf, action_dev,
                            (const float *)e->d_env_off, e->N);
     else if (e->use_coop)
@@ -1985,6 +1985,16 @@ extern "C" int parc_env_debug_dyn_stamps(double *out16) {
     HIPCHK(hipMemcpyFromSymbol(h, HIP_SYMBOL(parcdyn::g_dyn_stamps), sizeof(h)));
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(parcdyn::g_dyn_stamps), z, sizeof(z)));
     for (int i = 0; i < 16; ++i) out16[i] = (double)h[i];
+    return PARC_OK;
+}
+
+// Diagnostic: cycles per segment of k_dynamics_wave, per wave role [4][16], summed over all blocks since the last call.
+extern "C" int parc_env_debug_wave_stamps(double *out64) {
+    unsigned long long h[64], z[64] = {0};
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(h, HIP_SYMBOL(parcdyn::g_wave_stamps), sizeof(h)));
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(parcdyn::g_wave_stamps), z, sizeof(z)));
+    for (int i = 0; i < 64; ++i) out64[i] = (double)h[i];
     return PARC_OK;
 }
 #endif
