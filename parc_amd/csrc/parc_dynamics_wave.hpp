@@ -44,6 +44,8 @@ struct WaveTables {
     int child[WV_MAXLEN][WV_MAXLIMB];      // limb chain ids (1..)
     int npt[DYN_MAXB], pt0[DYN_MAXB];
     float brad[DYN_MAXB];
+    float bc[DYN_MAXB][3], brho[DYN_MAXB];  // bounding sphere of a body's collision spheres (body frame): centre = middle of the
+                                            // centres' box, radius includes the sphere radii
     int fac_off[1 + WV_MAXLIMB][WV_MAXLEN]; // first LDS slot of a body's joint-space factors (spherical 21, hinge 7, fixed / root 0)
     int fac_total;                          // slots in use (humanoid: 196)
 };
@@ -81,7 +83,24 @@ inline bool build_wave_tables(const DynModel &M, const CoopTables &C, WaveTables
         W.early[c] = pos > 0;
         W.child[pos][W.nchild[pos]++] = c;
     }
-    for (int b = 0; b < M.B; ++b) { W.npt[b] = C.npt[b]; W.pt0[b] = C.pt0[b]; W.brad[b] = C.brad[b]; }
+    for (int b = 0; b < M.B; ++b) {
+        W.npt[b] = C.npt[b]; W.pt0[b] = C.pt0[b]; W.brad[b] = C.brad[b];
+        float lo[3] = {0.f, 0.f, 0.f}, hi[3] = {0.f, 0.f, 0.f};
+        for (int i = 0; i < C.npt[b]; ++i)
+            for (int a = 0; a < 3; ++a) {
+                const float v = M.col_pos[C.pt0[b] + i][a];
+                if (i == 0 || v < lo[a]) lo[a] = v;
+                if (i == 0 || v > hi[a]) hi[a] = v;
+            }
+        float rho = 0.f;
+        for (int a = 0; a < 3; ++a) W.bc[b][a] = 0.5f * (lo[a] + hi[a]);
+        for (int i = 0; i < C.npt[b]; ++i) {
+            const float *q = M.col_pos[C.pt0[b] + i];
+            const float d = sqrtf((q[0] - W.bc[b][0]) * (q[0] - W.bc[b][0]) + (q[1] - W.bc[b][1]) * (q[1] - W.bc[b][1]) + (q[2] - W.bc[b][2]) * (q[2] - W.bc[b][2]));
+            if (d + M.col_r[C.pt0[b] + i] > rho) rho = d + M.col_r[C.pt0[b] + i];
+        }
+        W.brho[b] = rho * 1.0001f + 1e-6f;
+    }
     W.helper = -1;
     for (int c = 2; c < C.nchain; ++c) if (W.early[c] && W.att_slot[0] >= 0) { W.helper = c - 1; break; }
     int off = 0;
@@ -102,6 +121,7 @@ inline bool build_wave_tables(const DynModel &M, const CoopTables &C, WaveTables
 // Even slots = work segments, odd slots = the barrier wait that follows (see the WSTAMP calls in the substep loop).
 #ifdef PARC_STAMPS
 __device__ unsigned long long g_wave_stamps[4][16];
+__device__ unsigned long long g_wave_cnt[16][8]; // per body: lanes, near lanes, waves with a near lane, hit lanes, hit bits, slow lanes, pass-2 iterations, waves
 #define WSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); wacc[i] += t_ - wlast; wlast = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
 // pin: the 27 values of (IA, pA) must be complete before the stamp that follows (keeps arithmetic from sinking past it)
 #define WPIN(IA_, pA_) do { for (int i_ = 0; i_ < 21; ++i_) asm volatile("" : "+v"((IA_).s[i_])); for (int i_ = 0; i_ < 6; ++i_) asm volatile("" : "+v"((pA_).a[i_])); } while (0)
@@ -155,6 +175,10 @@ __device__ __forceinline__ void wv_fk_body(const DynModel &M, int b, WvBody &B, 
     }
     B.bq = pq; B.r = pr; B.vel = pv; B.cJ = cJ;
 }
+
+#ifndef WV_PASS1_UNROLL
+#define WV_PASS1_UNROLL _Pragma("unroll 4")
+#endif
 
 struct WvCtx { // per-lane constants of the control step
     const float *s_patch, *s_pmax, *s_pmax3; // + lane
@@ -238,76 +262,128 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
     WPIN(IA, pA);
     WSTAMP(12);
     // contacts.  A body whose bounding sphere clears every column its collision spheres could touch is skipped
-    // (exact: those contributions are zero).
+    // (exact: those contributions are zero).  The sphere centres lie within brho of the bounding centre, i.e. (brho < one
+    // cell) in the 3x3 cells around its cell, and each touches at most the columns one cell further: the 5x5 window.
     v3 fsum = mk(0.f, 0.f, 0.f);
-    const float brad = W.brad[b];
-    bool near = true;
+    const float brho = W.brho[b];
     float hmax = 3.0e38f; // highest column any sphere of this body can touch (+inf when the 5x5 window is not applicable)
     {
-        const int bx = cell_of(r.x + rootp.x + X.eo0, T.min_x, T.dx) - X.pox, by = cell_of(r.y + rootp.y + X.eo1, T.min_y, T.dy) - X.poy;
-        if (brad < X.cell_min && bx >= 2 && bx < DYN_PATCH - 2 && by >= 2 && by < DYN_PATCH - 2) {
+        const v3 cb = r + mulv(R, mk(W.bc[b][0], W.bc[b][1], W.bc[b][2]));
+        const int bx = cell_of(cb.x + rootp.x + X.eo0, T.min_x, T.dx) - X.pox, by = cell_of(cb.y + rootp.y + X.eo1, T.min_y, T.dy) - X.poy;
+        if (brho < X.cell_min && bx >= 2 && bx < DYN_PATCH - 2 && by >= 2 && by < DYN_PATCH - 2) {
             hmax = X.s_pmax[((bx - 2) * WV_PI + by - 2) * 64];
-            if (r.z + rootp.z + X.eo2 - brad > hmax) near = false;
+            if (cb.z + rootp.z + X.eo2 - brho > hmax) hmax = -3.0e38f; // clears everything: no point survives the test below
         }
     }
 #ifdef WV_EXP_NOCONTACT
-    near = false;
+    hmax = -3.0e38f;
 #endif
-    if (near) {
-        // Narrow phase.  A sphere can only touch the column of its own cell and the columns of the neighbours on the sides
-        // whose face is closer than its radius (for rad < half a cell: at most the x-side, the y-side and their diagonal;
-        // the far sides are at least half a cell away).  Everything is culled with ONE look-up of the 3x3 running maximum
-        // around the sphere's cell; the decision whether a candidate is a contact stays with sphere_vs_column / the
-        // penetration sign, so the result equals the exhaustive 9-column test of parc_dynamics.hpp.
-        const int npt = W.npt[b], pt0 = W.pt0[b];
-        const float hx = 0.5f * T.dx, hy = 0.5f * T.dy;
+    // Narrow phase in two passes.  A sphere can only touch the column of its own cell and the columns of the neighbours on
+    // the sides whose face is closer than its radius (for rad < half a cell: at most the x-side, the y-side and their
+    // diagonal; the far sides are at least half a cell away).
+    //   pass 1 (straight-line code, two points per iteration so that their table loads and LDS look-ups overlap): ONE
+    //          look-up of the 3x3 running maximum around the sphere's cell decides whether the point can touch anything;
+    //          survivors set a bit;
+    //   pass 2: only points that survived in some lane are evaluated; whether a candidate is a contact stays with
+    //          sphere_vs_column / the penetration sign, so the result equals the exhaustive 9-column test of
+    //          parc_dynamics.hpp.
+    // Lanes with a point outside the staged patch (or a sphere wider than a cell) take the exhaustive path below.
+    const int npt = W.npt[b], pt0 = W.pt0[b];
+    const float hx = 0.5f * T.dx, hy = 0.5f * T.dy;
+    unsigned hit = 0u;
+    bool slow = false;
+    if (__any(hmax > -1.0e38f)) {
+        auto cull_point = [&](int pi, bool valid) __attribute__((always_inline)) {
+            const int kp = pt0 + (valid ? pi : 0);
+            const v3 x = r + mulv(R, mk(M.col_pos[kp][0], M.col_pos[kp][1], M.col_pos[kp][2]));
+            const v3 g = mk(x.x + rootp.x + X.eo0, x.y + rootp.y + X.eo1, x.z + rootp.z + X.eo2);
+            const float rad = M.col_r[kp];
+            const float zlo = g.z - rad;
+            const int pa_ = cell_of(g.x, T.min_x, T.dx) - X.pox, pb_ = cell_of(g.y, T.min_y, T.dy) - X.poy;
+            const bool inp = pa_ >= 1 && pa_ < DYN_PATCH - 1 && pb_ >= 1 && pb_ < DYN_PATCH - 1;
+            const bool fast = inp && rad + 2e-3f < X.cell_min * 0.5f;
+            const int pac = pa_ < 1 ? 1 : (pa_ > DYN_PATCH - 2 ? DYN_PATCH - 2 : pa_), pbc = pb_ < 1 ? 1 : (pb_ > DYN_PATCH - 2 ? DYN_PATCH - 2 : pb_);
+            float m3 = X.s_pmax3[((pac - 1) * WV_P3 + pbc - 1) * 64];
+            asm volatile("" : "+v"(m3)); // the look-up is issued unconditionally (clamped address): nothing to branch around
+            const bool low = valid && !(zlo > hmax);
+            hit |= ((fast && low && !(zlo > m3)) ? 1u : 0u) << pi;
+            slow = slow || (low && !fast);
+        };
+        for (int pi = 0; pi < npt; pi += 2) { cull_point(pi, true); cull_point(pi + 1, pi + 1 < npt); }
+    }
+#ifdef WV_EXP_NOSLOW
+    slow = false;
+#endif
+#ifdef PARC_STAMPS
+    {
+        const unsigned long long m_near = __ballot(hmax > -1.0e38f), m_hit = __ballot(hit != 0u && !slow), m_slow = __ballot(slow);
+        int bits = __popc(slow ? 0u : hit);
+        for (int off = 32; off >= 1; off >>= 1) bits += __shfl_xor(bits, off, 64);
+        int it2 = 0;
+        for (int pi = 0; pi < npt; ++pi) if (__any(!slow && ((hit >> pi) & 1u))) ++it2;
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&g_wave_cnt[b][0], 64ull); atomicAdd(&g_wave_cnt[b][1], (unsigned long long)__popcll(m_near));
+            atomicAdd(&g_wave_cnt[b][2], m_near ? 1ull : 0ull); atomicAdd(&g_wave_cnt[b][3], (unsigned long long)__popcll(m_hit));
+            atomicAdd(&g_wave_cnt[b][4], (unsigned long long)bits); atomicAdd(&g_wave_cnt[b][5], (unsigned long long)__popcll(m_slow));
+            atomicAdd(&g_wave_cnt[b][6], (unsigned long long)it2); atomicAdd(&g_wave_cnt[b][7], 1ull);
+        }
+    }
+#endif
+    if (slow) hit = 0u;
+    for (int pi = 0; pi < npt; ++pi) {
+        const bool mine = (hit >> pi) & 1u;
+        if (!__any(mine)) continue; // uniform
+        if (mine) {
+            const int kp = pt0 + pi;
+            const v3 x = r + mulv(R, mk(M.col_pos[kp][0], M.col_pos[kp][1], M.col_pos[kp][2]));
+            const v3 g = mk(x.x + rootp.x + X.eo0, x.y + rootp.y + X.eo1, x.z + rootp.z + X.eo2);
+            const float rad = M.col_r[kp];
+            const float zlo = g.z - rad;
+            const int ix = cell_of(g.x, T.min_x, T.dx), iy = cell_of(g.y, T.min_y, T.dy);
+            const int pa_ = ix - X.pox, pb_ = iy - X.poy;
+            const float top0 = X.s_patch[(pa_ * DYN_PATCH + pb_) * 64];
+            const v3 vpt = s6lin(B.vel) + cross(s6ang(B.vel), x);
+            const float pen0 = rad + top0 - g.z;
+            if (pen0 > 0.f) wv_contact_own(M, dt, x, vpt, pen0, IA, pA, fsum);
+            const float ex = g.x - (T.min_x + (float)ix * T.dx), ey = g.y - (T.min_y + (float)iy * T.dy);
+            const float lim = rad + 1e-3f; // slack >> the rounding of the cell centres: it only admits candidates
+            const bool nx = hx - fabsf(ex) < lim, ny = hy - fabsf(ey) < lim;
+            if (nx || ny) {
+                const int sx = ex >= 0.f ? 1 : -1, sy = ey >= 0.f ? 1 : -1;
+                for (int c = 0; c < 3; ++c) { // x side, y side, diagonal
+                    const bool want = c == 0 ? nx : (c == 1 ? ny : (nx && ny));
+                    if (!want) continue;
+                    const int ox_ = c == 1 ? 0 : sx, oy_ = c == 0 ? 0 : sy;
+                    const float top = X.s_patch[((pa_ + ox_) * DYN_PATCH + pb_ + oy_) * 64];
+                    if (!(top > top0 + 1e-3f) || zlo > top) continue; // only higher neighbours act as walls / step edges
+                    v3 n;
+                    const float pen = sphere_vs_column(T, g, rad, ix + ox_, iy + oy_, top, n);
+                    if (pen > 0.f) wv_contact_generic(M, dt, x, vpt, pen, n, IA, pA, fsum);
+                }
+            }
+        }
+    }
+    if (slow) { // exhaustive test of every point, heights from the patch where it covers them, else from global memory
         for (int pi = 0; pi < npt; ++pi) {
             const int kp = pt0 + pi;
             const v3 x = r + mulv(R, mk(M.col_pos[kp][0], M.col_pos[kp][1], M.col_pos[kp][2]));
             const v3 g = mk(x.x + rootp.x + X.eo0, x.y + rootp.y + X.eo1, x.z + rootp.z + X.eo2);
             const float rad = M.col_r[kp];
             const float zlo = g.z - rad;
-            if (zlo > hmax) continue; // e.g. the upper corners of a foot that stands on the ground
+            if (zlo > hmax) continue;
             const int ix = cell_of(g.x, T.min_x, T.dx), iy = cell_of(g.y, T.min_y, T.dy);
             const int pa_ = ix - X.pox, pb_ = iy - X.poy;
             const bool inp = pa_ >= 1 && pa_ < DYN_PATCH - 1 && pb_ >= 1 && pb_ < DYN_PATCH - 1;
-            if (inp && rad + 2e-3f < X.cell_min * 0.5f) {
-                if (zlo > X.s_pmax3[((pa_ - 1) * WV_P3 + pb_ - 1) * 64]) continue; // above every column it could reach
-                const float top0 = X.s_patch[(pa_ * DYN_PATCH + pb_) * 64];
-                const v3 vpt = s6lin(B.vel) + cross(s6ang(B.vel), x);
-                const float pen0 = rad + top0 - g.z;
-                if (pen0 > 0.f) wv_contact_own(M, dt, x, vpt, pen0, IA, pA, fsum);
-                const float ex = g.x - (T.min_x + (float)ix * T.dx), ey = g.y - (T.min_y + (float)iy * T.dy);
-                const float lim = rad + 1e-3f; // slack >> the rounding of the cell centres: it only admits candidates
-                const bool nx = hx - fabsf(ex) < lim, ny = hy - fabsf(ey) < lim;
-                if (nx || ny) {
-                    const int sx = ex >= 0.f ? 1 : -1, sy = ey >= 0.f ? 1 : -1;
-                    for (int c = 0; c < 3; ++c) { // x side, y side, diagonal
-                        const bool want = c == 0 ? nx : (c == 1 ? ny : (nx && ny));
-                        if (!want) continue;
-                        const int ox_ = c == 1 ? 0 : sx, oy_ = c == 0 ? 0 : sy;
-                        const float top = X.s_patch[((pa_ + ox_) * DYN_PATCH + pb_ + oy_) * 64];
-                        if (!(top > top0 + 1e-3f) || zlo > top) continue; // only higher neighbours act as walls / step edges
-                        v3 n;
-                        const float pen = sphere_vs_column(T, g, rad, ix + ox_, iy + oy_, top, n);
-                        if (pen > 0.f) wv_contact_generic(M, dt, x, vpt, pen, n, IA, pA, fsum);
-                    }
-                }
+            const float top0 = inp ? X.s_patch[(pa_ * DYN_PATCH + pb_) * 64] : hf_at(T, ix, iy);
+            const v3 vpt = s6lin(B.vel) + cross(s6ang(B.vel), x);
+            for (int nb = 0; nb < 9; ++nb) {
+                const int ox_ = (nb % 3) - 1, oy_ = (nb / 3) - 1;
+                const float top = nb == 4 ? top0 : (inp ? X.s_patch[((pa_ + ox_) * DYN_PATCH + pb_ + oy_) * 64] : hf_at(T, ix + ox_, iy + oy_));
+                if (!(nb == 4 || top > top0 + 1e-3f) || zlo > top) continue;
+                v3 n;
+                const float pen = sphere_vs_column(T, g, rad, ix + ox_, iy + oy_, top, n);
+                if (pen > 0.f) wv_contact_generic(M, dt, x, vpt, pen, n, IA, pA, fsum);
             }
-#ifndef WV_EXP_NOSLOW
-            else { // outside the staged patch (or a sphere wider than a cell): exhaustive test, heights from global memory
-                const float top0 = inp ? X.s_patch[(pa_ * DYN_PATCH + pb_) * 64] : hf_at(T, ix, iy);
-                const v3 vpt = s6lin(B.vel) + cross(s6ang(B.vel), x);
-                for (int nb = 0; nb < 9; ++nb) {
-                    const int ox_ = (nb % 3) - 1, oy_ = (nb / 3) - 1;
-                    const float top = nb == 4 ? top0 : (inp ? X.s_patch[((pa_ + ox_) * DYN_PATCH + pb_ + oy_) * 64] : hf_at(T, ix + ox_, iy + oy_));
-                    if (!(nb == 4 || top > top0 + 1e-3f) || zlo > top) continue;
-                    v3 n;
-                    const float pen = sphere_vs_column(T, g, rad, ix + ox_, iy + oy_, top, n);
-                    if (pen > 0.f) wv_contact_generic(M, dt, x, vpt, pen, n, IA, pA, fsum);
-                }
-            }
-#endif
         }
     }
     B.fcon = fsum;

@@ -1997,6 +1997,16 @@ extern "C" int parc_env_debug_wave_stamps(double *out64) {
     for (int i = 0; i < 64; ++i) out64[i] = (double)h[i];
     return PARC_OK;
 }
+
+// Diagnostic: contact-cull statistics of k_dynamics_wave per body [16][8] (see g_wave_cnt), cleared by the call.
+extern "C" int parc_env_debug_wave_counts(double *out128) {
+    unsigned long long h[128], z[128] = {0};
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(h, HIP_SYMBOL(parcdyn::g_wave_cnt), sizeof(h)));
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(parcdyn::g_wave_cnt), z, sizeof(z)));
+    for (int i = 0; i < 128; ++i) out128[i] = (double)h[i];
+    return PARC_OK;
+}
 #endif
 
 extern "C" int parc_env_profile_step(ParcEnv *e, const float *action_dev, void *stream, int32_t iters, float *avg_ms, float *avg_post_ms) {

@@ -16,13 +16,16 @@ env = HipParkourEnv(cfg, n, "cuda:0", False, seed=1, mirror_ref_state=False, ena
 env.reset()
 lo, hi = env._action_bound_low, env._action_bound_high
 torch.manual_seed(0)
-ACT = (0.5 * (hi + lo) + 0.025 * (hi - lo) * torch.randn(n, env._char_dof_pos.shape[1], device="cuda:0")).contiguous()
+ACT = (0.5 * (hi + lo) + 0.05 * 0.5 * (hi - lo) * torch.randn(n, env._char_dof_pos.shape[1], device="cuda:0")).contiguous()
 for _ in range(20):
     env.step(ACT); env.reset_done()
 torch.cuda.synchronize()
 a = (C.c_double * 64)()
 env._lib.parc_env_debug_wave_stamps.argtypes = [C.POINTER(C.c_double)]
 env._lib.parc_env_debug_wave_stamps(a)  # clear
+_c = (C.c_double * 128)()
+env._lib.parc_env_debug_wave_counts.argtypes = [C.POINTER(C.c_double)]
+env._lib.parc_env_debug_wave_counts(_c)  # clear
 iters = 20
 for _ in range(iters):
     env.step(ACT); env.reset_done()
@@ -38,3 +41,12 @@ for w in range(4):
     row["total"] = sum(row.values())
     out[f"wave{w}"] = row
 print(json.dumps({"envs": n, "cycles_per_control_step": out}, indent=1))
+c = (C.c_double * 128)()
+env._lib.parc_env_debug_wave_counts.argtypes = [C.POINTER(C.c_double)]
+env._lib.parc_env_debug_wave_counts(c)
+bn = env._kin_char_model.get_body_names()
+print("%-18s %8s %8s %8s %8s %8s %8s" % ("body", "near", "wv_near", "hit", "bits/hit", "slow", "it2/wave"), file=sys.stderr)
+for b in range(len(bn)):
+    r = [c[b * 8 + i] for i in range(8)]
+    if r[0] == 0: continue
+    print("%-18s %8.4f %8.4f %8.4f %8.2f %8.5f %8.2f" % (bn[b], r[1] / r[0], r[2] / r[7], r[3] / r[0], r[4] / max(r[3], 1), r[5] / r[0], r[6] / r[7]), file=sys.stderr)
