@@ -1,21 +1,28 @@
 #!/usr/bin/env python3
-"""Headline benchmark: env-steps/s of the motion-tracking env step at 65 536 envs per GPU.
+"""Headline benchmark: env-steps/s of the motion-tracking env step at 65 536 envs (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            # launches its own N ranks (one process per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W                # or runs as one of N externally launched ranks
 
 A "step" is what the PPO rollout does to the env per control step (base_agent.py:348-370): ``env.step(action)``
-followed by the reset of the envs that finished.  Envs shard across ranks with no data-path collective
-(``scaling: weak``: every GPU owns ``--envs`` envs; offsets follow the global env index).  Rank 0 prints ONE JSON line.
+followed by the reset of the envs that finished.  Envs shard across ranks as contiguous global-index ranges with no
+data-path collective.  ``--scaling strong`` (default, the north-star metric): ``--envs`` is the TOTAL (65 536 ->
+8 192 per GPU at 8 GPUs); ``--scaling weak``: ``--envs`` per GPU.  Rank 0 prints ONE JSON line.
 
-The JSON carries ``roofline`` (algorithmic HBM bytes of the step kernel / its hipEvent-measured duration, against
-the 8 TB/s HBM peak) and, at N=1, ``cpu_baseline`` (the CPU oracle — a scalar C port of the reference step, first
-pinned against the reference's golden vectors — timed on this host's cores on a bounded sample).
+``--ppo 1`` adds the learner's collective to every 32 steps (cfg 4): 40 all-reduces of the 42.56 MB fp32 gradient bucket
+over RCCL, i.e. env-steps/s of a PPO iteration's env + communication legs (the policy network itself is PyTorch's and is
+not part of this benchmark).
+
+The JSON carries ``roofline`` (dominant kernel; hipEvent-measured duration on the launch stream) and, at N=1,
+``cpu_baseline`` (the CPU oracle — a scalar C port of the reference step, pinned against the reference's golden vectors —
+timed on this host's cores on a bounded sample).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import threading
 import time
@@ -28,23 +35,70 @@ BYTES_KINEMATIC = 5772   # read state 276 + contact forces 180 + bookkeeping 24;
 BYTES_DYNAMICS = 6340    # + action 112, state write-back 276, contact-force write 180
 BYTES_DYN_KERNEL = 844   # k_dynamics alone: state 276 + action 112 in, state 276 + contact forces 180 out
 HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: 8 TB/s spec
+VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector peak = 1024 SIMDs x 64 lanes x 2 flop / 2 cycles x 2.4 GHz
+GRAD_BUCKET_FLOATS = 10638877  # parameters of the default actor/critic (dm_agent_default.yaml), one flat fp32 bucket = 42.56 MB
+PPO_STEPS_PER_ITER, PPO_ALLREDUCES_PER_ITER = 32, 40  # dm_agent_default.yaml: steps_per_iter, update_epochs x minibatches
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
+    ap.add_argument("--envs", type=int, default=65536, help="total envs (--scaling strong) or envs per GPU (--scaling weak)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--config", default=os.path.join(REPO, "data/configs/tracker_config/dm_env_default.yaml"))
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--motions", type=int, default=0,
-                    help="replicate the bundled clips to this many library entries (SURVEY 8(d) cfg 3: 1024); 0 = the 5 clips as they are")
+                    help="synthetic library of this many entries from the bundled clips (SURVEY 8(d): cfg 3 = 1024, cfg 4/5 = 16384); 0 = the clips as they are")
+    ap.add_argument("--yaw", type=int, default=0, help="with --motions: 1 = pseudo-clips yaw-rotated by 2 pi i / M, weights = clip length (cfg 4/5)")
     ap.add_argument("--graph", type=int, default=0,
                     help="1: step + reset_done as one hipGraph launch (parc_env_step_reset_graph); kernel timings are then taken from a short separate run")
     ap.add_argument("--dynamics", type=int, default=1, help="1: full step (rigid-body dynamics + contact), 0: kinematic step only")
-    return ap.parse_args()
+    ap.add_argument("--ppo", type=int, default=0, help="1: add the 40 x 42.56 MB gradient all-reduces of a PPO iteration to every 32 steps (cfg 4)")
+    return ap.parse_args(argv)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# launcher: the parent never touches the GPU; it starts one fresh process per rank and relays rank 0's JSON line
+# ----------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n, argv, script=None, extra_env=None):
+    """Start ``n`` ranks of ``script`` (default: this file) with torchrun-style env vars, wait, return (rc, rank-0 stdout)."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if extra_env:
+            env.update(extra_env)
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        p.wait()
+        rc = rc or p.returncode
+    return rc, out0
+
+
+def shard_sizes(envs, world, scaling):
+    """(envs per GPU, total envs): strong = ``envs`` is the total, split evenly; weak = ``envs`` per GPU."""
+    if scaling == "strong":
+        if envs % world != 0:
+            raise ValueError("--envs must be divisible by --gpus for strong scaling")
+        return envs // world, envs
+    return envs, envs * world
 
 
 def cpu_baseline(env, seconds, dynamics_on, actions):
@@ -61,7 +115,8 @@ def cpu_baseline(env, seconds, dynamics_on, actions):
                           cg["dof_idx"], int(cg["dof_size"]))
     sc = env._scene
     n = env.get_num_envs()
-    clips = helpers.load_clips([c.name for c in sc.clips])
+    clips = [dict(name=c.name, root_pos=c.root_pos, root_rot=c.root_rot, joint_rot=c.joint_rot, contacts=c.contacts, fps=c.fps,
+                  loop_mode=c.loop_mode) for c in sc.clips]
     lib = oracle.mlib_create(oc, clips, [c.weight for c in sc.clips])
     ocfg = helpers.default_cfg(oracle, n, sc.ray_points, sc.env_offsets, sc.grid.motion_offsets)
     ter = oracle.make_terrain(sc.grid.terrain.hf, sc.grid.terrain.min_point, sc.grid.terrain.dxdy)
@@ -110,60 +165,62 @@ def cpu_baseline(env, seconds, dynamics_on, actions):
                       "(scalar, -O2, one thread per core), same scene and state"}
 
 
-def main():
-    a = parse()
+def _profile_json(name):
+    p = os.path.join(REPO, "profiles", name)
+    return json.load(open(p)) if os.path.exists(p) else None
+
+
+def worker(a):
     import ctypes as C
     import torch
     from parc_amd import lib as L
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    # rehearsal switches for a one-GPU box (never set by the driver): all ranks on cuda:0, gloo for the barrier / max
-    backend = os.environ.get("PARC_BENCH_BACKEND", "nccl")
-    if os.environ.get("PARC_BENCH_SHARE_GPU"):
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    # rehearsal switch for a one-GPU box (never set by the driver): all ranks on cuda:0, gloo for the barrier / max
+    share = bool(os.environ.get("PARC_BENCH_SHARE_GPU"))
+    backend = os.environ.get("PARC_BENCH_BACKEND", "gloo" if share else "nccl")
+    if share:
         local = 0
+    dist = None
     if world > 1:
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
         else:
             dist.init_process_group(backend)
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     from parc_amd.envs.hip_parkour_env import HipParkourEnv
     from parc_amd.util import path_loader
     cfg = path_loader.load_config(a.config)
-    if a.motions > 0:  # synthetic large library: names suffixed, same content (symlinks), weights unchanged
-        import tempfile, yaml
-        src = path_loader.load_config(str(path_loader.resolve_path(cfg["env"]["dm"]["motion_file"])))["motions"]
+    if a.motions > 0:  # synthetic library generated in memory (parc_amd/util/synth_dataset.py)
+        import tempfile
+        from parc_amd.util import synth_dataset
         d = tempfile.mkdtemp(prefix=f"parc_bench_lib_r{rank}_")
-        ents = []
-        for i in range(a.motions):
-            m = src[i % len(src)]
-            f = str(path_loader.resolve_path(m["file"]))
-            dst = os.path.join(d, os.path.splitext(os.path.basename(f))[0] + f"_r{i:05d}.pkl")
-            os.symlink(f, dst)
-            ents.append({"file": dst, "weight": m.get("weight", 1.0)})
-        with open(os.path.join(d, "motions.yaml"), "w") as fh:
-            yaml.safe_dump({"motions": ents}, fh)
-        cfg["env"]["dm"]["motion_file"] = os.path.join(d, "motions.yaml")
+        base = str(path_loader.resolve_path(cfg["env"]["dm"]["motion_file"]))
+        cfg["env"]["dm"]["motion_file"] = synth_dataset.write_spec(os.path.join(d, "motions.yaml"), base, a.motions, yaw=bool(a.yaw))
         cfg["env"]["dm"].pop("terrain_save_path", None)
+    n_local, n_total = shard_sizes(a.envs, world, a.scaling)
     dyn = bool(a.dynamics)
     sys.stdout = sys.stderr if rank == 0 else open(os.devnull, "w")  # the only stdout line is the JSON below
-    env = HipParkourEnv(cfg, a.envs, dev, False, env_id_base=rank * a.envs, total_envs=world * a.envs, seed=1234 + rank,
+    env = HipParkourEnv(cfg, n_local, dev, False, env_id_base=rank * n_local, total_envs=n_total, seed=1234 + rank,
                         mirror_ref_state=False, enable_dynamics=dyn)
     dynamics_on = bool(env._scene.cfg.enable_dynamics)
     mode = cfg["env"]["dm"].get("terrain_build_mode", "square")
     ncl = len(env._scene.clips)
-    lib_desc = (f"{a.motions} library entries (the bundled clips replicated)" if a.motions > 0 else
+    lib_desc = ((f"{a.motions} synthetic library entries (bundled clips " + ("yaw-rotated, weight = length)" if a.yaw else "replicated)")) if a.motions > 0 else
                 (f"{ncl} bundled clips" if ncl > 1 else f"clip {env._scene.clips[0].name}")) + \
                {"square": " on a square blocky grid", "wide": " on a wide blocky grid", "file": " on its own terrain"}.get(mode, "")
     D = env._char_dof_pos.shape[1]
     # untrained-policy actions (SURVEY §8(d) cfg 3): action-normalizer mean + N(0, 0.05^2) * std
     lo, hi = env._action_bound_low, env._action_bound_high
     mean, std = 0.5 * (hi + lo), 0.5 * (hi - lo)
-    actions = [mean + 0.05 * std * torch.randn(a.envs, D, device=dev) for _ in range(4)]
+    actions = [mean + 0.05 * std * torch.randn(n_local, D, device=dev) for _ in range(4)]
     env.reset()
+    grad = None
+    if a.ppo:
+        grad = torch.zeros(GRAD_BUCKET_FLOATS, dtype=torch.float32, device=dev if backend == "nccl" else "cpu")
 
     def one_step(i):
         if a.graph:
@@ -171,6 +228,11 @@ def main():
         else:
             env.step(actions[i & 3])
             env.reset_done()
+        if grad is not None and (i + 1) % PPO_STEPS_PER_ITER == 0:
+            for _ in range(PPO_ALLREDUCES_PER_ITER):  # the learner's gradient bucket, once per minibatch (optimizer.py)
+                if dist is not None:
+                    dist.all_reduce(grad, op=dist.ReduceOp.SUM)
+                grad.mul_(1.0 / world)
 
     for i in range(a.warmup):
         one_step(i)
@@ -205,43 +267,59 @@ def main():
     else:
         assert nst.value == a.steps
     dyn_ms, post_ms = float(dms.value), float(pms.value)
-    # HBM traffic of k_env_post from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs;
-    # FETCH_SIZE doubled per the gfx950 correction).  Only valid for the configuration it was collected on.
+
+    # Counter-derived figures come from the committed rocprofv3 --pmc passes (profiles/, collected on the 65 536-env
+    # default configuration in separate runs), NOT from this run; they are attached only to that configuration.
+    at_profiled_cfg = n_local == 65536 and a.motions == 0
     post_traffic = None
-    pmc_path = os.path.join(REPO, "profiles", "r01_pmc_hbm_traffic.json")
-    if os.path.exists(pmc_path) and a.envs == 65536:
-        pmc = json.load(open(pmc_path))
+    pmc = _profile_json("r02_pmc_hbm_traffic.json") or _profile_json("r01_pmc_hbm_traffic.json")
+    if pmc and at_profiled_cfg:
         k = "void k_env_post<0>"
         post_traffic = (2.0 * pmc["FETCH_SIZE_KiB_avg_per_dispatch"][k] + pmc["WRITE_SIZE_KiB_avg_per_dispatch"][k]) * 1024.0
-    post_gbs = BYTES_KINEMATIC * a.envs / (post_ms * 1e-3) / 1e9
-    if dynamics_on:   # dominant kernel = k_dynamics: state 276 + action 112 in, state 276 + contact forces 180 out
+    post_gbs = BYTES_KINEMATIC * n_local / (post_ms * 1e-3) / 1e9
+    obs_kernel = {"kernel": "k_env_prep + k_env_post<MODE_STEP>", "bound": "hbm", "kernel_ms": post_ms, "achieved": post_gbs, "peak": HBM_PEAK_GBS,
+                  "unit": "GB/s", "frac": post_gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_env_step": BYTES_KINEMATIC,
+                  "traffic": post_traffic, "traffic_source": "profiles/ (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate run), not measured in this run"}
+    if dynamics_on and dyn_ms >= post_ms:
+        # dominant kernel = the dynamics: VALU-issue bound (rigid-body recursion in registers), 844 B of HBM per env-step.
         kname = env._lib.parc_env_dynamics_kernel(env._handle).decode()
-        kms, bytes_per, traffic = dyn_ms, BYTES_DYN_KERNEL, None
-        dpmc = os.path.join(REPO, "profiles", "r01_pmc_dynamics.json")
-        if os.path.exists(dpmc) and a.envs == 65536:
-            dj = json.load(open(dpmc))
-            if dj.get("kernel") == kname:
-                traffic = 2.0 * dj["FETCH_SIZE_KiB"] * 1024.0 + dj["WRITE_SIZE_KiB"] * 1024.0
+        hbm_gbs = BYTES_DYN_KERNEL * n_local / (dyn_ms * 1e-3) / 1e9
+        dj = _profile_json("r02_pmc_dynamics.json")
+        valu = traffic = None
+        if dj and dj.get("kernel") == kname and at_profiled_cfg:
+            traffic = 2.0 * dj["FETCH_SIZE_KiB"] * 1024.0 + dj["WRITE_SIZE_KiB"] * 1024.0
+            valu = dj.get("SQ_INSTS_VALU")  # wave-level VALU instructions per launch
+        roof = {"bound": "valu", "kernel": kname, "kernel_ms": dyn_ms, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "achieved": None, "frac": None, "traffic": traffic,
+                "traffic_source": "profiles/r02_pmc_dynamics.json (separate rocprofv3 --pmc passes), not measured in this run",
+                "definition": "achieved = wave-level VALU instructions per launch (SQ_INSTS_VALU, profiles/) x 128 flop (64 lanes x FMA) / measured kernel time: "
+                              "the share of the fp32 vector issue slots the kernel fills, an upper bound on its useful flops",
+                "hbm": {"achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS,
+                        "algorithmic_bytes_per_env_step": BYTES_DYN_KERNEL},
+                "obs_kernel": obs_kernel}
+        if valu:
+            roof["achieved"] = valu * 128.0 / (dyn_ms * 1e-3) / 1e12
+            roof["frac"] = roof["achieved"] / VALU_PEAK_TFLOPS
+        else:  # no counter file for this configuration: fall back to the HBM figure the contract asks for
+            roof.update({"bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS,
+                         "note": "VALU-bound kernel; no SQ counter file for this configuration, HBM fraction reported instead"})
     else:
-        kname, kms, bytes_per, traffic = "k_env_prep + k_env_post<MODE_STEP>", post_ms, BYTES_KINEMATIC, post_traffic
-    achieved = bytes_per * a.envs / (kms * 1e-3) / 1e9
+        roof = dict(obs_kernel)
+        if dynamics_on:
+            hbm_gbs = BYTES_DYN_KERNEL * n_local / (dyn_ms * 1e-3) / 1e9
+            roof["dynamics_kernel"] = {"kernel": env._lib.parc_env_dynamics_kernel(env._handle).decode(), "kernel_ms": dyn_ms, "bound": "valu",
+                                       "hbm": {"achieved": hbm_gbs, "frac": hbm_gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_env_step": BYTES_DYN_KERNEL}}
+    roof["whole_step_algorithmic_bytes"] = BYTES_DYNAMICS if dynamics_on else BYTES_KINEMATIC
     out = {
-        "metric": "env-steps/s", "value": a.envs * world * a.steps / dt, "unit": "env-steps/s", "n_gpus": world,
+        "metric": "env-steps/s", "value": n_total * a.steps / dt, "unit": "env-steps/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": a.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": ("full step (dynamics + obs/reward/done)" if dynamics_on else "kinematic step (ref slerp + FK + 441-ray hf + obs + reward + done), no physics")
-                               + f", {a.envs} envs per GPU, " + lib_desc + ", reset of finished envs included",
-                   "envs_per_gpu": a.envs, "total_envs": a.envs * world, "dynamics": dynamics_on, "parallelism": f"env-shard x{world}",
+                               + f", {n_total} envs total = {n_local} per GPU, " + lib_desc + ", reset of finished envs included"
+                               + (f", + {PPO_ALLREDUCES_PER_ITER} x {GRAD_BUCKET_FLOATS * 4 / 1e6:.2f} MB gradient all-reduces per {PPO_STEPS_PER_ITER} steps ({backend})" if a.ppo else ""),
+                   "envs_per_gpu": n_local, "total_envs": n_total, "dynamics": dynamics_on, "parallelism": f"env-shard x{world}",
                    "launch": "hipGraph (step + reset_done)" if a.graph else "stream launches"},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "kernel": kname, "kernel_ms": kms, "algorithmic_bytes_per_env_step": bytes_per,
-                     "note": ("the dynamics kernel is VALU-issue / latency bound (rigid-body recursion, ~47k VALU instructions per wave at 1 wave per SIMD; "
-                              "profiles/r01_pmc_dynamics.json), far below the HBM ceiling by construction (SURVEY 8d); obs_kernel is the HBM-bound one")
-                             if dynamics_on else "",
-                     "obs_kernel": {"kernel": "k_env_prep + k_env_post<MODE_STEP>", "kernel_ms": post_ms, "achieved": post_gbs,
-                                    "frac": post_gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_env_step": BYTES_KINEMATIC,
-                                    "traffic": post_traffic},
-                     "whole_step_algorithmic_bytes": BYTES_DYNAMICS if dynamics_on else BYTES_KINEMATIC},
+        "roofline": roof,
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(env, a.cpu_seconds, dynamics_on, actions)
@@ -250,6 +328,21 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def main():
+    a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ:  # not under torchrun: be our own launcher (no GPU call in this process)
+        import torch
+        ngpu = torch.cuda.device_count()  # does not initialise the GPU
+        extra = {}
+        if ngpu < a.gpus:
+            if not os.environ.get("PARC_BENCH_SHARE_GPU"):
+                sys.exit(f"bench.py: --gpus {a.gpus} but {ngpu} GPU(s) visible (set PARC_BENCH_SHARE_GPU=1 to rehearse all ranks on one GPU)")
+        rc, out0 = launch_ranks(a.gpus, sys.argv[1:], extra_env=extra)
+        sys.stdout.write(out0)
+        sys.exit(rc)
+    worker(a)
 
 
 if __name__ == "__main__":

@@ -222,6 +222,24 @@ int parc_forward_kinematics(ParcEnv *env, const float *root_pos_dev, const float
 int parc_calc_motion_frame(ParcEnv *env, const int32_t *motion_ids_dev, const float *times_dev, int32_t n,
                            float *root_pos_dev, float *root_rot_dev, float *root_vel_dev, float *root_ang_vel_dev,
                            float *joint_rot_dev, float *dof_vel_dev, float *contacts_dev, void *stream);
+/* TEST ENTRY POINT: one of the quaternion device functions of parc_math.hpp (the restatements of torch_util.py:6-530 that
+ * the kernels inline) applied element-wise to device arrays, so that the reference's edge-case vectors (w < 0, tiny angles,
+ * |sin| < 1e-3, |cos| >= 1, exp maps beyond pi; tests/golden/quat_ops.npz) reach the DEVICE code and not only the CPU oracle.
+ * a: [n][4] (ops on quaternions) or [n][3] (PARC_QOP_NORMALIZE3 / EXP_MAP_TO_QUAT / AA_TO_QUAT axis / ROTATE_2D vector in
+ * the first two components); b: second operand ([n][4], or [n][3] for QUAT_ROTATE) or NULL; t: [n] scalar (slerp
+ * parameter / angle) or NULL; out: [n][PARC_QOP out width: 4, 3, 6 (tan-norm), 1 or 2]. */
+enum {
+    PARC_QOP_MUL = 0, PARC_QOP_ROTATE = 1, PARC_QOP_CONJ = 2, PARC_QOP_POS = 3, PARC_QOP_NORMALIZE3 = 4, PARC_QOP_TO_AXIS_ANGLE = 5 /* out [n][4]: axis, angle */,
+    PARC_QOP_AA_TO_QUAT = 6, PARC_QOP_EXP_MAP_TO_QUAT = 7, PARC_QOP_TO_EXP_MAP = 8, PARC_QOP_DIFF_ANGLE = 9, PARC_QOP_NORMALIZE = 10,
+    PARC_QOP_TO_TAN_NORM = 11, PARC_QOP_SLERP = 12, PARC_QOP_HEADING = 13, PARC_QOP_HEADING_QUAT_INV = 14, PARC_QOP_DIFF = 15,
+    PARC_QOP_ROTATE_2D = 16
+};
+int parc_test_quat_op(int32_t op, const float *a_dev, const float *b_dev, const float *t_dev, int32_t n, float *out_dev, void *stream);
+
+/* The compiler flags the library was built with (set by the build recipe): the loader refuses a library whose flags lack
+ * -fno-slp-vectorize / -ffp-contract=off (toolchain note). */
+const char *parc_build_flags(void);
+
 /* copy the derived frame tables back (tests): [F][3],[F][3],[F][D] */
 int parc_env_get_frame_vel_tables(ParcEnv *env, float *root_vel_host, float *root_ang_vel_host, float *dof_vel_host);
 

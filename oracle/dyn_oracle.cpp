@@ -21,7 +21,9 @@ void orc_dyn_destroy(void *m) { delete (DynModel *)m; }
 
 void orc_dyn_set_contact(void *m, float kn, float dn, float dtang, float mu) {
     DynModel *M = (DynModel *)m;
+    const float vmax = M->pen_cap * M->kn / M->dn; // keep the depenetration speed the model was built with
     M->kn = kn; M->dn = dn; M->dtang = dtang; M->mu = mu;
+    M->pen_cap = vmax * dn / kn;
 }
 void orc_dyn_set_gravity(void *m, float g) { ((DynModel *)m)->gravity_z = g; }
 void orc_dyn_set_gains_scale(void *m, float s) {
@@ -36,6 +38,16 @@ void orc_dyn_get_mass(void *m, float *mass, float *com, float *inertia, float *t
         for (int k = 0; k < 6; ++k) inertia[6 * b + k] = M->inertia[b][k];
     }
     *total = M->total_mass; *ncol = M->ncol;
+}
+
+// geometry of the own-cell contact on a 0.4 m grid whose cell (0,0) is centred at the origin; tops5 = own, +x, -x, +y, -y
+float orc_own_column_contact(const float *tops5, float x, float y, float z, float r, float *n_out) {
+    DynTerrain T; T.hf = nullptr; T.X = 1; T.Y = 1; T.min_x = 0.f; T.min_y = 0.f; T.dx = 0.4f; T.dy = 0.4f;
+    v3 n;
+    const float pen = own_column_contact(T, mk(x, y, z), r, 0, 0, tops5[0], [&](int ox, int oy) {
+        return ox == 1 ? tops5[1] : (ox == -1 ? tops5[2] : (oy == 1 ? tops5[3] : tops5[4])); }, n);
+    n_out[0] = n.x; n_out[1] = n.y; n_out[2] = n.z;
+    return pen;
 }
 
 // state arrays are [n][...] row-major like the env tensors

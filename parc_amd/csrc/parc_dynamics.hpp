@@ -82,6 +82,7 @@ struct DynModel {
     float gravity_z, dt;         // dt of one solver substep
     int nsub;                    // substeps per control step (sim_steps * substeps)
     float kn, dn, dtang, mu;     // contact stiffness / normal damping / tangential damping / friction
+    float pen_cap;               // penetration beyond which the contact spring saturates (PhysX max_depenetration_velocity, see fill_dyn_model)
     float lim_k, lim_d;          // joint-limit penalty
     float max_ang_vel, ang_damping;
     float total_mass;
@@ -256,6 +257,54 @@ PARC_HD float sphere_vs_column(const DynTerrain &T, v3 s, float r, int ix, int i
     return r + (top - s.z);
 }
 
+// The sphere's OWN cell (its centre lies inside the footprint of cell (ix,iy), column top `top0`).
+//   centre above the surface: normal +z, pen = r - (s.z - top0);
+//   centre inside the solid: it leaves along the cheapest way out -- up through the top (top0 - s.z), or sideways through a
+//   face whose neighbour column is lower: distance to the face + what is left to climb on the other side.  This is what a
+//   blocky mesh with real vertical wall faces does to a shape that penetrates a wall a little; pushing such a point out
+//   through the top (metres away for a wall) launched bodies that had crossed a wall face or touched a step riser.
+// `top_of(ox, oy)` returns the top of the neighbour column at cell offset (ox, oy).
+template <class TopOf>
+PARC_HD float own_column_contact(const DynTerrain &T, v3 s, float r, int ix, int iy, float top0, TopOf top_of, v3 &n) {
+    n = mk(0.f, 0.f, 1.f);
+    if (s.z >= top0) return r - (s.z - top0);
+    float best = top0 - s.z;
+    const float ex = s.x - (T.min_x + (float)ix * T.dx), ey = s.y - (T.min_y + (float)iy * T.dy);
+    const float hx = 0.5f * T.dx, hy = 0.5f * T.dy;
+    float pen = best;
+    PARC_UNROLL
+    for (int f = 0; f < 4; ++f) {
+        const int ox = f == 0 ? 1 : (f == 1 ? -1 : 0), oy = f == 2 ? 1 : (f == 3 ? -1 : 0);
+        const float tn = top_of(ox, oy);
+        if (!(tn < top0 - 1e-3f)) continue;
+        const float d = f == 0 ? hx - ex : (f == 1 ? hx + ex : (f == 2 ? hy - ey : hy + ey));
+        const float climb = tn > s.z ? tn - s.z : 0.f;
+        if (d + climb < best) { best = d + climb; pen = d; n = mk((float)ox, (float)oy, 0.f); }
+    }
+    return pen + r;
+}
+
+// One contact (point at x relative to O with velocity vpt, penetration pen along the unit normal n): explicit force into
+// pA and the force report, implicit term dt X^T (beta 1 + (bn - beta) n n^T) X into IA.
+PARC_HD void contact_apply(const DynModel &M, float dt, v3 x, v3 vpt, float pen, v3 n, sym6 &IA, s6 &pA, v3 &fsum) {
+    const bool capped = pen > M.pen_cap;
+    if (capped) pen = M.pen_cap;
+    const float vn = dot(vpt, n);
+    float fn = M.kn * pen - M.dn * vn;
+    if (fn < 0.f) fn = 0.f;
+    const v3 vt = vpt - vn * n;
+    const float vtm = DYN_SQRT(dot(vt, vt));
+    float beta = M.dtang;
+    if (beta * vtm > M.mu * fn) beta = vtm > 1e-9f ? M.mu * fn * DYN_RCP(vtm) : 0.f; // secant of the Coulomb cone
+    const v3 f = fn * n - beta * vt;
+    const v3 no = cross(x, f);
+    pA.a[0] -= no.x; pA.a[1] -= no.y; pA.a[2] -= no.z; pA.a[3] -= f.x; pA.a[4] -= f.y; pA.a[5] -= f.z;
+    fsum = fsum + f;
+    const float bn = fn > 0.f ? (M.dn + (capped ? 0.f : dt * M.kn)) : 0.f; // only while pushing; a saturated spring adds no stiffness
+    add_inertia(IA, dt * beta, x, nullptr);
+    symrank1(IA, dt * (bn - beta), s6mk(cross(x, n), n));
+}
+
 // ---------------------------------------------------------------- per-env step
 struct DynState { // pointers to this env's rows
     float *root_pos, *root_rot, *root_vel, *root_ang_vel, *dof_pos, *dof_vel;
@@ -357,25 +406,11 @@ PARC_HD void dyn_control_step(const DynModel &M, const DynTerrain &T, const DynS
                 if (!own && !(top > top0 + 1e-3f)) continue; // only higher neighbours act as walls / step edges
                 if (g.z - rad > top) continue;
                 v3 n;
-                const float pen = sphere_vs_column(T, g, rad, jx, jy, top, n);
+                const float pen = own ? own_column_contact(T, g, rad, ix, iy, top0, [&](int ox, int oy) { return patch_h(T, patch, ix + ox, iy + oy); }, n)
+                                      : sphere_vs_column(T, g, rad, jx, jy, top, n);
                 if (!(pen > 0.f)) continue;
-                const float vn = dot(vpt, n);
-                float fn = M.kn * pen - M.dn * vn;
-                if (fn < 0.f) fn = 0.f;
-                v3 vt = vpt - vn * n;
-                const float vtm = sqrtf(dot(vt, vt));
-                float beta = M.dtang;
-                if (beta * vtm > M.mu * fn) beta = vtm > 1e-9f ? M.mu * fn / vtm : 0.f; // secant of the Coulomb cone
-                v3 f = fn * n - beta * vt;
-                // explicit part
-                v3 no = cross(x, f);
-                pA[i].a[0] -= no.x; pA[i].a[1] -= no.y; pA[i].a[2] -= no.z; pA[i].a[3] -= f.x; pA[i].a[4] -= f.y; pA[i].a[5] -= f.z;
-                fcon[i] = fcon[i] + f;
-                // implicit part: dt * X^T (beta 1 + (bn - beta) n n^T) X, bn = dn + dt*kn (only while pushing)
-                const float bn = fn > 0.f ? (M.dn + dt * M.kn) : 0.f;
-                add_inertia(IA[i], dt * beta, x, nullptr);
-                s6 wv = s6mk(cross(x, n), n);
-                symrank1(IA[i], dt * (bn - beta), wv);
+                // explicit force + implicit part dt * X^T (beta 1 + (bn - beta) n n^T) X, bn = dn + dt*kn (only while pushing)
+                contact_apply(M, dt, x, vpt, pen, n, IA[i], pA[i], fcon[i]);
             }
         }
         // ---- inward pass ------------------------------------------------------------------------------------
@@ -656,6 +691,10 @@ inline void fill_dyn_model(DynModel &M, const ParcCharModel &cm, const ParcDynam
     M.gravity_z = dp.gravity_z;
     // contact compliance (re-authored solver; PhysX's rigid contact has no such parameters)
     M.kn = 5.0e4f; M.dn = 5.0e2f; M.dtang = 1.0e4f; M.mu = dp.friction;
+    // PhysX bounds the speed at which a penetration is pushed out (max_depenetration_velocity, ig_env.py:150-160 /
+    // dm_env_default.yaml sim.physx).  A spring-damper contact pushes out at v = kn pen / dn once spring and damper balance,
+    // so the same bound is a cap on the penetration the spring sees: pen_cap = v_max dn / kn (0.1 m for 10 m/s).
+    M.pen_cap = (dp.max_depenetration_velocity > 0.f ? dp.max_depenetration_velocity : 10.f) * M.dn / M.kn;
     M.lim_k = 1.0e3f; M.lim_d = 5.0e1f;
     M.max_ang_vel = dp.max_angular_velocity > 0.f ? dp.max_angular_velocity : 100.f;
     M.ang_damping = dp.angular_damping;

@@ -326,22 +326,11 @@ __global__ __launch_bounds__(64, 1) void k_dynamics_coop(const DynModel *__restr
                                 if (!own && !(top > top0 + 1e-3f)) continue;
                                 if (g.z - rad > top) continue;
                                 v3 n;
-                                const float pen = sphere_vs_column(T, g, rad, ix + ox_, iy + oy_, top, n);
+                                const float pen = own ? own_column_contact(T, g, rad, ix, iy, top0, [&](int ox, int oy) {
+                                                            return inp ? s_patch[el][(pa_ + ox) * DYN_PATCH + pb_ + oy] : hf_at(T, ix + ox, iy + oy); }, n)
+                                                      : sphere_vs_column(T, g, rad, ix + ox_, iy + oy_, top, n);
                                 if (!(pen > 0.f)) continue;
-                                const float vn = dot(vpt, n);
-                                float fn = Mg.kn * pen - Mg.dn * vn;
-                                if (fn < 0.f) fn = 0.f;
-                                const v3 vt = vpt - vn * n;
-                                const float vtm = sqrtf(dot(vt, vt));
-                                float beta = Mg.dtang;
-                                if (beta * vtm > Mg.mu * fn) beta = vtm > 1e-9f ? Mg.mu * fn / vtm : 0.f;
-                                const v3 f = fn * n - beta * vt;
-                                const v3 no = cross(x, f);
-                                pA.a[0] -= no.x; pA.a[1] -= no.y; pA.a[2] -= no.z; pA.a[3] -= f.x; pA.a[4] -= f.y; pA.a[5] -= f.z;
-                                fsum = fsum + f;
-                                const float bn = fn > 0.f ? (Mg.dn + dt * Mg.kn) : 0.f;
-                                add_inertia(IA, dt * beta, x, nullptr);
-                                symrank1(IA, dt * (bn - beta), s6mk(cross(x, n), n));
+                                contact_apply(Mg, dt, x, vpt, pen, n, IA, pA, fsum);
                             }
                         }
 #pragma unroll

@@ -186,29 +186,16 @@ struct WvCtx { // per-lane constants of the control step
     float eo0, eo1, eo2, cell_min, dt;
 };
 
-// One contact (point at x relative to O, velocity vpt, penetration pen along the unit normal n): explicit force into pA,
-// implicit term dt X^T (beta 1 + (bn - beta) n n^T) X into IA (parc_dynamics.hpp, dyn_control_step, "contacts").
+// a contact with a general normal: the shared statement of parc_dynamics.hpp
 __device__ __forceinline__ void wv_contact_generic(const DynModel &M, float dt, v3 x, v3 vpt, float pen, v3 n, sym6 &IA, s6 &pA, v3 &fsum) {
-    const float vn = dot(vpt, n);
-    float fn = M.kn * pen - M.dn * vn;
-    if (fn < 0.f) fn = 0.f;
-    const v3 vt = vpt - vn * n;
-    const float vtm = DYN_SQRT(dot(vt, vt));
-    float beta = M.dtang;
-    if (beta * vtm > M.mu * fn) beta = vtm > 1e-9f ? M.mu * fn * DYN_RCP(vtm) : 0.f;
-    const v3 f = fn * n - beta * vt;
-    const v3 no = cross(x, f);
-    pA.a[0] -= no.x; pA.a[1] -= no.y; pA.a[2] -= no.z; pA.a[3] -= f.x; pA.a[4] -= f.y; pA.a[5] -= f.z;
-    fsum = fsum + f;
-    const float bn = fn > 0.f ? (M.dn + dt * M.kn) : 0.f;
-    add_inertia(IA, dt * beta, x, nullptr);
-    symrank1(IA, dt * (bn - beta), s6mk(cross(x, n), n));
+    contact_apply(M, dt, x, vpt, pen, n, IA, pA, fsum);
 }
 
-// The same for the column of the sphere's OWN cell, where the normal is +z by construction: sphere_vs_column's two
-// branches both give n = (0,0,1), pen = rad + top - z for a centre that lies inside the cell's footprint.  The rank-1
-// term then has three non-zero components, w = (x.y, -x.x, 0, 0, 0, 1): 6 entries of IA instead of 21.
+// contact_apply specialised for the normal +z (the sphere's own column, unless it leaves a wall sideways): the rank-1 term
+// then has three non-zero components, w = (x.y, -x.x, 0, 0, 0, 1): 6 entries of IA instead of 21.
 __device__ __forceinline__ void wv_contact_own(const DynModel &M, float dt, v3 x, v3 vpt, float pen, sym6 &IA, s6 &pA, v3 &fsum) {
+    const bool capped = pen > M.pen_cap;
+    if (capped) pen = M.pen_cap;
     float fn = M.kn * pen - M.dn * vpt.z;
     if (fn < 0.f) fn = 0.f;
     const float vtm = DYN_SQRT(vpt.x * vpt.x + vpt.y * vpt.y);
@@ -218,7 +205,7 @@ __device__ __forceinline__ void wv_contact_own(const DynModel &M, float dt, v3 x
     const v3 no = cross(x, f);
     pA.a[0] -= no.x; pA.a[1] -= no.y; pA.a[2] -= no.z; pA.a[3] -= f.x; pA.a[4] -= f.y; pA.a[5] -= f.z;
     fsum = fsum + f;
-    const float bn = fn > 0.f ? (M.dn + dt * M.kn) : 0.f;
+    const float bn = fn > 0.f ? (M.dn + (capped ? 0.f : dt * M.kn)) : 0.f;
     add_inertia(IA, dt * beta, x, nullptr);
     const float k = dt * (bn - beta);
     IA.s[sidx(0, 0)] += k * x.y * x.y; IA.s[sidx(0, 1)] -= k * x.y * x.x; IA.s[sidx(0, 5)] += k * x.y;
@@ -344,7 +331,14 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
             const float top0 = X.s_patch[(pa_ * DYN_PATCH + pb_) * 64];
             const v3 vpt = s6lin(B.vel) + cross(s6ang(B.vel), x);
             const float pen0 = rad + top0 - g.z;
-            if (pen0 > 0.f) wv_contact_own(M, dt, x, vpt, pen0, IA, pA, fsum);
+            if (g.z >= top0) { // centre above the surface: normal +z
+                if (pen0 > 0.f) wv_contact_own(M, dt, x, vpt, pen0, IA, pA, fsum);
+            } else {           // centre inside the solid: cheapest way out (own_column_contact), usually still +z
+                v3 n;
+                const float pen = own_column_contact(T, g, rad, ix, iy, top0, [&](int ox, int oy) { return X.s_patch[((pa_ + ox) * DYN_PATCH + pb_ + oy) * 64]; }, n);
+                if (n.z > 0.5f) wv_contact_own(M, dt, x, vpt, pen, IA, pA, fsum);
+                else wv_contact_generic(M, dt, x, vpt, pen, n, IA, pA, fsum);
+            }
             const float ex = g.x - (T.min_x + (float)ix * T.dx), ey = g.y - (T.min_y + (float)iy * T.dy);
             const float lim = rad + 1e-3f; // slack >> the rounding of the cell centres: it only admits candidates
             const bool nx = hx - fabsf(ex) < lim, ny = hy - fabsf(ey) < lim;
@@ -381,7 +375,9 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
                 const float top = nb == 4 ? top0 : (inp ? X.s_patch[((pa_ + ox_) * DYN_PATCH + pb_ + oy_) * 64] : hf_at(T, ix + ox_, iy + oy_));
                 if (!(nb == 4 || top > top0 + 1e-3f) || zlo > top) continue;
                 v3 n;
-                const float pen = sphere_vs_column(T, g, rad, ix + ox_, iy + oy_, top, n);
+                const float pen = nb == 4 ? own_column_contact(T, g, rad, ix, iy, top0, [&](int ox, int oy) {
+                                                return inp ? X.s_patch[((pa_ + ox) * DYN_PATCH + pb_ + oy) * 64] : hf_at(T, ix + ox, iy + oy); }, n)
+                                          : sphere_vs_column(T, g, rad, ix + ox_, iy + oy_, top, n);
                 if (pen > 0.f) wv_contact_generic(M, dt, x, vpt, pen, n, IA, pA, fsum);
             }
         }

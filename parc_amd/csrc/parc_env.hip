@@ -1945,6 +1945,63 @@ extern "C" int parc_calc_motion_frame(ParcEnv *e, const int32_t *ids, const floa
     return PARC_OK;
 }
 
+// ---- test entry point: the device quaternion functions, element-wise ------------------------------------------------
+__global__ void k_test_quat_op(int op, const float *__restrict__ a, const float *__restrict__ b, const float *__restrict__ t, int n, float *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Q4 qa = (op == PARC_QOP_NORMALIZE3 || op == PARC_QOP_EXP_MAP_TO_QUAT || op == PARC_QOP_AA_TO_QUAT || op == PARC_QOP_ROTATE_2D)
+                      ? mk4(a[3 * i], a[3 * i + 1], a[3 * i + 2], 0.f) : mk4(a[4 * i], a[4 * i + 1], a[4 * i + 2], a[4 * i + 3]);
+    const V3 va = mk3(qa.x, qa.y, qa.z);
+    Q4 qb = mk4(0.f, 0.f, 0.f, 1.f);
+    V3 vb = mk3(0.f, 0.f, 0.f);
+    if (b) {
+        if (op == PARC_QOP_ROTATE) vb = mk3(b[3 * i], b[3 * i + 1], b[3 * i + 2]);
+        else qb = mk4(b[4 * i], b[4 * i + 1], b[4 * i + 2], b[4 * i + 3]);
+    }
+    const float ts = t ? t[i] : 0.f;
+    auto put4 = [&](Q4 q) { out[4 * i] = q.x; out[4 * i + 1] = q.y; out[4 * i + 2] = q.z; out[4 * i + 3] = q.w; };
+    auto put3 = [&](V3 v) { out[3 * i] = v.x; out[3 * i + 1] = v.y; out[3 * i + 2] = v.z; };
+    switch (op) {
+    case PARC_QOP_MUL: put4(quat_mul(qa, qb)); break;
+    case PARC_QOP_ROTATE: put3(quat_rotate(qa, vb)); break;
+    case PARC_QOP_CONJ: put4(quat_conj(qa)); break;
+    case PARC_QOP_POS: put4(quat_pos(qa)); break;
+    case PARC_QOP_NORMALIZE3: put3(normalize3(va)); break;
+    case PARC_QOP_TO_AXIS_ANGLE: { V3 ax; float an; quat_to_axis_angle(qa, ax, an); put4(mk4(ax.x, ax.y, ax.z, an)); break; }
+    case PARC_QOP_AA_TO_QUAT: put4(axis_angle_to_quat(va, ts)); break;
+    case PARC_QOP_EXP_MAP_TO_QUAT: put4(exp_map_to_quat(va)); break;
+    case PARC_QOP_TO_EXP_MAP: put3(quat_to_exp_map(qa)); break;
+    case PARC_QOP_DIFF_ANGLE: out[i] = quat_diff_angle(qa, qb); break;
+    case PARC_QOP_NORMALIZE: put4(quat_normalize(qa)); break;
+    case PARC_QOP_TO_TAN_NORM: { float tn[6]; quat_to_tan_norm(qa, tn); for (int c = 0; c < 6; ++c) out[6 * i + c] = tn[c]; break; }
+    case PARC_QOP_SLERP: put4(slerp(qa, qb, ts)); break;
+    case PARC_QOP_HEADING: out[i] = calc_heading(qa); break;
+    case PARC_QOP_HEADING_QUAT_INV: put4(heading_quat_inv(calc_heading(qa))); break;
+    case PARC_QOP_DIFF: put4(quat_mul(qb, quat_conj(qa))); break; // torch_util.py:454 quat_diff(q0, q1) = q1 (x) conj(q0)
+    case PARC_QOP_ROTATE_2D: { // torch_util.py:651, as the ray loop of k_env_post evaluates it
+        const float ch = cosf(ts), sh = sinf(ts);
+        out[2 * i] = qa.x * ch - qa.y * sh; out[2 * i + 1] = qa.x * sh + qa.y * ch; break;
+    }
+    default: break;
+    }
+}
+
+extern "C" int parc_test_quat_op(int32_t op, const float *a, const float *b, const float *t, int32_t n, float *out, void *stream) {
+    if (!a || !out || n < 0 || op < 0 || op > PARC_QOP_ROTATE_2D) return fail(PARC_ERR_INVALID, "bad argument");
+    if ((op == PARC_QOP_MUL || op == PARC_QOP_ROTATE || op == PARC_QOP_DIFF_ANGLE || op == PARC_QOP_SLERP || op == PARC_QOP_DIFF) && !b)
+        return fail(PARC_ERR_INVALID, "this op needs a second operand");
+    if ((op == PARC_QOP_AA_TO_QUAT || op == PARC_QOP_SLERP || op == PARC_QOP_ROTATE_2D) && !t) return fail(PARC_ERR_INVALID, "this op needs the scalar operand");
+    if (n == 0) return PARC_OK;
+    hipLaunchKernelGGL(k_test_quat_op, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, (int)op, a, b, t, (int)n, out);
+    HIPCHK(hipGetLastError());
+    return PARC_OK;
+}
+
+#ifndef PARC_BUILD_FLAGS
+#define PARC_BUILD_FLAGS "unknown"
+#endif
+extern "C" const char *parc_build_flags(void) { return PARC_BUILD_FLAGS; }
+
 extern "C" int parc_env_get_frame_vel_tables(ParcEnv *e, float *root_vel, float *root_ang_vel, float *dof_vel) {
     if (!e || !e->have_motions) return fail(PARC_ERR_STATE, "load_motions first");
     HIPCHK(hipSetDevice(e->cfg.device));

@@ -94,6 +94,11 @@ def load():
         raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the env step.")
     lib = C.CDLL(LIB_PATH)
+    lib.parc_build_flags.restype = C.c_char_p
+    flags = lib.parc_build_flags().decode()
+    missing = [f for f in REQUIRED_BUILD_FLAGS if f not in flags.split()]
+    if missing:  # an SLP-vectorised k_dynamics_wave computes wrong inertias; contraction breaks the 1e-5 parity
+        raise RuntimeError(f"{LIB_PATH} was built with '{flags}': missing {missing}; rebuild with __graft_entry__.build()")
     lib.parc_last_error.restype = C.c_char_p
     vp = C.c_void_p
     lib.parc_env_create.argtypes = [C.POINTER(ParcEnvConfig), C.POINTER(vp)]
@@ -133,6 +138,7 @@ def load():
     lib.parc_env_set_kernel_timing.argtypes = [vp, C.c_int32]
     lib.parc_env_get_kernel_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]
     lib.parc_env_dynamics_kernel.argtypes = [vp]
+    lib.parc_test_quat_op.argtypes = [C.c_int32, vp, vp, vp, C.c_int32, vp, vp]
     lib.parc_env_dynamics_kernel.restype = C.c_char_p
     if lib.parc_abi_version() != ABI_VERSION:
         raise RuntimeError("libparc_env.so ABI version mismatch")
@@ -147,7 +153,14 @@ EXPORTED_SYMBOLS = [
     "parc_env_get_motion_info", "parc_env_set_rand_reset", "parc_env_set_start_time_fraction", "parc_dof_to_rot",
     "parc_rot_to_dof", "parc_forward_kinematics", "parc_calc_motion_frame", "parc_env_get_frame_vel_tables",
     "parc_env_profile_step", "parc_env_last_dynamics_ms", "parc_env_dynamics_kernel", "parc_env_set_kernel_timing", "parc_env_get_kernel_timing", "parc_env_record_bind", "parc_env_record_frame", "parc_env_set_episode_length", "parc_td_lambda_return", "parc_normalize_record", "parc_env_bind_action", "parc_env_get_buffers", "parc_env_step_reset_graph",
+    "parc_test_quat_op", "parc_build_flags",
 ]
+
+# parc_test_quat_op selectors (include/parc_env.h)
+QOP = {"mul": 0, "rotate": 1, "conj": 2, "pos": 3, "normalize3": 4, "to_axis_angle": 5, "aa_to_quat": 6, "exp_map_to_quat": 7,
+       "to_exp_map": 8, "diff_angle": 9, "normalize": 10, "to_tan_norm": 11, "slerp": 12, "heading": 13, "heading_quat_inv": 14,
+       "diff": 15, "rotate_2d": 16}
+REQUIRED_BUILD_FLAGS = ("-fno-slp-vectorize", "-ffp-contract=off")
 
 
 class ParcError(RuntimeError):

@@ -77,6 +77,16 @@ def load_clip(path: str, weight: float = 1.0) -> Clip:
 
 
 def load_motion_file(motion_file, verbose=True) -> List[Clip]:
+    mf = str(path_loader.resolve_path(motion_file))
+    if os.path.splitext(mf)[1] == ".yaml":
+        spec = path_loader.load_config(mf).get("synthetic")
+        if spec is not None:  # benchmark libraries generated in memory (parc_amd/util/synth_dataset.py)
+            from parc_amd.util import synth_dataset
+            base = load_motion_file(spec["base"], verbose=False)
+            yaw = bool(spec.get("yaw", True))
+            if verbose:
+                print("Synthetic library: {:d} clips from {:d} ({:s})".format(int(spec["count"]), len(base), "yaw-rotated" if yaw else "replicated"))
+            return synth_dataset.make_library(base, int(spec["count"]), yaw=yaw, pad=float(spec.get("pad", 3.2)), weight_by_length=yaw)
     files, weights = fetch_motion_files(motion_file)
     clips, names = [], set()
     for i, (f, w) in enumerate(zip(files, weights)):

