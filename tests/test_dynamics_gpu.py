@@ -210,3 +210,62 @@ def test_physx_recorded_trajectory_open_loop_replay():
     assert m["contact_agreement_feet"] > 0.65
     assert abs(m["foot_contact_rate_sim"] - m["foot_contact_rate_ref"]) < 0.25
     assert m["reward_mean_tracked"] > 0.8
+
+
+def test_cfg5_shard_synthetic_full_dataset_shape(tmp_path):
+    """BASELINE cfg 5 on one GPU's shard: 16 384 envs (= 131 072 / 8) on the M = 16 384 pseudo-clip library of SURVEY 8(d)
+    (bundled clip i mod 5, yaw 2 pi i / M, weight = clip length), per-env motion-terrain offsets + curriculum resets, dynamics on.
+    Size-independent properties: the library is what the generator promises, resets land the character on ITS tile of the
+    16 384-tile grid standing on the (rotated) ground, sampling follows the weights, the step stays finite and deterministic."""
+    import torch
+    from gpu_helpers import default_config, to_np
+    from conftest import DATA
+    from parc_amd.envs.hip_parkour_env import HipParkourEnv
+    from parc_amd.util import synth_dataset
+    n, M = 16384, 16384
+    cfg = default_config()
+    cfg["env"]["dm"]["motion_file"] = synth_dataset.write_spec(str(tmp_path / "motions.yaml"), os.path.join(DATA, "motion_terrains", "motions_bundled.yaml"), M, yaw=True)
+    mk = lambda: HipParkourEnv(cfg, n, "cuda:0", False, seed=77, enable_dynamics=True, mirror_ref_state=True, env_id_base=0, total_envs=131072)
+    env = mk()
+    sc = env._scene
+    assert len(sc.clips) == M and sc.grid.motion_offsets.shape == (M, 1, 2)
+    lengths = np.array([(c.num_frames - 1) / c.fps for c in sc.clips])
+    assert np.allclose([c.weight for c in sc.clips], lengths)                       # weight = clip length
+    assert np.allclose(to_np(env._motion_lengths), lengths, atol=1e-5)
+    yaw0 = 2.0 * np.arctan2(sc.clips[0].root_rot[0, 2], sc.clips[0].root_rot[0, 3])  # clip 5 k = clip 0 turned by 2 pi 5k / M
+    k = 1000
+    yawk = 2.0 * np.arctan2(sc.clips[5 * k].root_rot[0, 2], sc.clips[5 * k].root_rot[0, 3])
+    assert abs(((yawk - yaw0) - 2.0 * np.pi * 5 * k / M + np.pi) % (2.0 * np.pi) - np.pi) < 2e-2
+    tables_mb = (sum(c.num_frames for c in sc.clips) * 512 + sc.grid.terrain.hf.nbytes) / 1e6
+    assert tables_mb > 512.0, tables_mb   # frame records + grid exceed the 256 MB Infinity Cache: the table-miss row of SURVEY 8(d)
+    obs, _ = env.reset()
+    torch.cuda.synchronize()
+    assert torch.isfinite(obs).all()
+    # every env sits on the tile of ITS motion: global xy inside the tile's footprint
+    mid = to_np(env._motion_ids).astype(np.int64)
+    gxy = to_np(env._char_root_pos)[:, :2] + sc.env_offsets[:, :2]
+    ter = np.array([[c.terrain.min_point[0], c.terrain.min_point[1], c.terrain.hf.shape[0] * c.terrain.dx, c.terrain.hf.shape[1] * c.terrain.dx] for c in sc.clips])
+    lo = sc.grid.motion_offsets[mid, 0] + ter[mid, :2]
+    assert np.all(gxy >= lo - 0.5) and np.all(gxy <= lo + ter[mid, 2:] + 0.5)
+    # and stands on the rotated ground: the height sample under the root (ray point (0, 0) is index 2 of every 63-point ray)
+    under = to_np(env._ray_hfs)[:, 3 * 63 + 2]
+    # (the bundled clips cross gaps: in 22-30 % of their frames the root is over a drop deeper than the 3 m clamp)
+    assert -1.1 < np.median(under) < -0.6 and np.quantile(under, 0.95) < -0.3 and np.mean(under <= -2.99) < 0.36, \
+        (np.median(under), np.quantile(under, 0.95), np.mean(under <= -2.99))
+    # sampling ~ weight (fail rates are 1): the five base clips' shares
+    share = np.array([lengths[mid % 5 == b].size for b in range(5)], np.float64) / n
+    expect = np.array([lengths[b::5].sum() for b in range(5)]) / lengths.sum()
+    assert np.abs(share - expect).max() < 5.0 * np.sqrt(0.25 / n) + 1e-3, (share, expect)
+    assert len(np.unique(mid)) > 0.55 * n                                          # 16 384 draws from 16 384 entries: ~63 % distinct
+    gen = torch.Generator(device="cuda:0"); gen.manual_seed(5)
+    acts = [_bench_actions(env, gen) for _ in range(6)]
+    for a in acts:
+        env.step(a); env.reset_done()
+    _finite_state(env)
+    env2 = mk()
+    env2.reset()
+    for a in acts:
+        env2.step(a); env2.reset_done()
+    assert torch.equal(env._obs_buf, env2._obs_buf) and torch.equal(env._motion_ids, env2._motion_ids)  # same seed: bit-identical
+    fr = env.get_fail_rates().numpy()
+    assert fr.shape == (M,) and fr.min() > 0.0 and fr.max() <= 1.0 and (fr < 1.0).any()

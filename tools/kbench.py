@@ -31,3 +31,10 @@ sys.stdout = sys.__stdout__
 print(json.dumps({"lib": os.environ.get("PARC_ENV_LIB", "in-tree"), "envs": n, "step_ms": round(1e3 * dt / steps, 4),
                   "dyn_ms": round(kt["dynamics_ms"], 4), "obs_ms": round(kt["obs_ms"], 4),
                   "Menv_steps_s": round(n * steps / dt / 1e6, 2)}))
+if os.environ.get("PARC_STAMPS"):  # -DPARC_STAMPS build: mean cycles per phase of k_env_post over the envs of the last step
+    import ctypes as C
+    arr = (C.c_double * 8)()
+    env._lib.parc_env_debug_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    rc = env._lib.parc_env_debug_stamps(env._handle, arr)
+    names = ["prefetch+fill", "rays", "rows+contacts", "FK", "key obs", "reward+done", "obs stream", "-"]
+    print(json.dumps({"rc": rc, "post_cycles": {k: round(v) for k, v in zip(names, arr)}, "total": round(sum(arr))}))
