@@ -182,8 +182,11 @@ __device__ __forceinline__ void wv_fk_body(const DynModel &M, int b, WvBody &B, 
 
 struct WvCtx { // per-lane constants of the control step
     const float *s_patch, *s_pmax, *s_pmax3; // + lane
-    int pox, poy;
-    float eo0, eo1, eo2, cell_min, dt;
+    int pox, poy;             // global cell index of patch cell (0,0)
+    float cell_min, dt;
+    DynTerrain Tp;            // the PATCH FRAME: origin = centre of patch cell (DYN_PATCH/2, DYN_PATCH/2), so cell_of(., Tp) is a patch index.
+                              // Every horizontal coordinate of the contact code lives in this frame (|x| < 2 m, ulp 2.4e-7 m); the
+                              // reference's env-local coordinates reach ~1 km at 65 536 envs (ulp 6e-5 m), see the kernel prologue.
 };
 
 // a contact with a general normal: the shared statement of parc_dynamics.hpp
@@ -217,6 +220,7 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
                                                 const m3 &R, v3 rootp, sym6 &IA, s6 &pA WSTAMP_PARAMS) {
     const v3 r = B.r;
     const float dt = X.dt;
+    const DynTerrain &Tp = X.Tp;
     {
         const v3 cm = r + mulv(R, mk(M.com[b][0], M.com[b][1], M.com[b][2]));
         const float Ib[3][3] = {{M.inertia[b][0], M.inertia[b][3], M.inertia[b][4]}, {M.inertia[b][3], M.inertia[b][1], M.inertia[b][5]},
@@ -256,10 +260,10 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
     float hmax = 3.0e38f; // highest column any sphere of this body can touch (+inf when the 5x5 window is not applicable)
     {
         const v3 cb = r + mulv(R, mk(W.bc[b][0], W.bc[b][1], W.bc[b][2]));
-        const int bx = cell_of(cb.x + rootp.x + X.eo0, T.min_x, T.dx) - X.pox, by = cell_of(cb.y + rootp.y + X.eo1, T.min_y, T.dy) - X.poy;
+        const int bx = cell_of(cb.x + rootp.x, Tp.min_x, Tp.dx), by = cell_of(cb.y + rootp.y, Tp.min_y, Tp.dy);
         if (brho < X.cell_min && bx >= 2 && bx < DYN_PATCH - 2 && by >= 2 && by < DYN_PATCH - 2) {
             hmax = X.s_pmax[((bx - 2) * WV_PI + by - 2) * 64];
-            if (cb.z + rootp.z + X.eo2 - brho > hmax) hmax = -3.0e38f; // clears everything: no point survives the test below
+            if (cb.z + rootp.z - brho > hmax) hmax = -3.0e38f; // clears everything: no point survives the test below
         }
     }
 #ifdef WV_EXP_NOCONTACT
@@ -276,17 +280,17 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
     //          parc_dynamics.hpp.
     // Lanes with a point outside the staged patch (or a sphere wider than a cell) take the exhaustive path below.
     const int npt = W.npt[b], pt0 = W.pt0[b];
-    const float hx = 0.5f * T.dx, hy = 0.5f * T.dy;
+    const float hx = 0.5f * Tp.dx, hy = 0.5f * Tp.dy;
     unsigned hit = 0u;
     bool slow = false;
     if (__any(hmax > -1.0e38f)) {
         auto cull_point = [&](int pi, bool valid) __attribute__((always_inline)) {
             const int kp = pt0 + (valid ? pi : 0);
             const v3 x = r + mulv(R, mk(M.col_pos[kp][0], M.col_pos[kp][1], M.col_pos[kp][2]));
-            const v3 g = mk(x.x + rootp.x + X.eo0, x.y + rootp.y + X.eo1, x.z + rootp.z + X.eo2);
+            const v3 g = x + rootp;
             const float rad = M.col_r[kp];
             const float zlo = g.z - rad;
-            const int pa_ = cell_of(g.x, T.min_x, T.dx) - X.pox, pb_ = cell_of(g.y, T.min_y, T.dy) - X.poy;
+            const int pa_ = cell_of(g.x, Tp.min_x, Tp.dx), pb_ = cell_of(g.y, Tp.min_y, Tp.dy);
             const bool inp = pa_ >= 1 && pa_ < DYN_PATCH - 1 && pb_ >= 1 && pb_ < DYN_PATCH - 1;
             const bool fast = inp && rad + 2e-3f < X.cell_min * 0.5f;
             const int pac = pa_ < 1 ? 1 : (pa_ > DYN_PATCH - 2 ? DYN_PATCH - 2 : pa_), pbc = pb_ < 1 ? 1 : (pb_ > DYN_PATCH - 2 ? DYN_PATCH - 2 : pb_);
@@ -323,11 +327,10 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
         if (mine) {
             const int kp = pt0 + pi;
             const v3 x = r + mulv(R, mk(M.col_pos[kp][0], M.col_pos[kp][1], M.col_pos[kp][2]));
-            const v3 g = mk(x.x + rootp.x + X.eo0, x.y + rootp.y + X.eo1, x.z + rootp.z + X.eo2);
+            const v3 g = x + rootp;
             const float rad = M.col_r[kp];
             const float zlo = g.z - rad;
-            const int ix = cell_of(g.x, T.min_x, T.dx), iy = cell_of(g.y, T.min_y, T.dy);
-            const int pa_ = ix - X.pox, pb_ = iy - X.poy;
+            const int pa_ = cell_of(g.x, Tp.min_x, Tp.dx), pb_ = cell_of(g.y, Tp.min_y, Tp.dy); // patch indices = cell indices of the patch frame
             const float top0 = X.s_patch[(pa_ * DYN_PATCH + pb_) * 64];
             const v3 vpt = s6lin(B.vel) + cross(s6ang(B.vel), x);
             const float pen0 = rad + top0 - g.z;
@@ -335,11 +338,11 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
                 if (pen0 > 0.f) wv_contact_own(M, dt, x, vpt, pen0, IA, pA, fsum);
             } else {           // centre inside the solid: cheapest way out (own_column_contact), usually still +z
                 v3 n;
-                const float pen = own_column_contact(T, g, rad, ix, iy, top0, [&](int ox, int oy) { return X.s_patch[((pa_ + ox) * DYN_PATCH + pb_ + oy) * 64]; }, n);
+                const float pen = own_column_contact(Tp, g, rad, pa_, pb_, top0, [&](int ox, int oy) { return X.s_patch[((pa_ + ox) * DYN_PATCH + pb_ + oy) * 64]; }, n);
                 if (n.z > 0.5f) wv_contact_own(M, dt, x, vpt, pen, IA, pA, fsum);
                 else wv_contact_generic(M, dt, x, vpt, pen, n, IA, pA, fsum);
             }
-            const float ex = g.x - (T.min_x + (float)ix * T.dx), ey = g.y - (T.min_y + (float)iy * T.dy);
+            const float ex = g.x - (Tp.min_x + (float)pa_ * Tp.dx), ey = g.y - (Tp.min_y + (float)pb_ * Tp.dy);
             const float lim = rad + 1e-3f; // slack >> the rounding of the cell centres: it only admits candidates
             const bool nx = hx - fabsf(ex) < lim, ny = hy - fabsf(ey) < lim;
             if (nx || ny) {
@@ -351,7 +354,7 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
                     const float top = X.s_patch[((pa_ + ox_) * DYN_PATCH + pb_ + oy_) * 64];
                     if (!(top > top0 + 1e-3f) || zlo > top) continue; // only higher neighbours act as walls / step edges
                     v3 n;
-                    const float pen = sphere_vs_column(T, g, rad, ix + ox_, iy + oy_, top, n);
+                    const float pen = sphere_vs_column(Tp, g, rad, pa_ + ox_, pb_ + oy_, top, n);
                     if (pen > 0.f) wv_contact_generic(M, dt, x, vpt, pen, n, IA, pA, fsum);
                 }
             }
@@ -361,12 +364,12 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
         for (int pi = 0; pi < npt; ++pi) {
             const int kp = pt0 + pi;
             const v3 x = r + mulv(R, mk(M.col_pos[kp][0], M.col_pos[kp][1], M.col_pos[kp][2]));
-            const v3 g = mk(x.x + rootp.x + X.eo0, x.y + rootp.y + X.eo1, x.z + rootp.z + X.eo2);
+            const v3 g = x + rootp;
             const float rad = M.col_r[kp];
             const float zlo = g.z - rad;
             if (zlo > hmax) continue;
-            const int ix = cell_of(g.x, T.min_x, T.dx), iy = cell_of(g.y, T.min_y, T.dy);
-            const int pa_ = ix - X.pox, pb_ = iy - X.poy;
+            const int pa_ = cell_of(g.x, Tp.min_x, Tp.dx), pb_ = cell_of(g.y, Tp.min_y, Tp.dy);
+            const int ix = X.pox + pa_, iy = X.poy + pb_; // global cell (heights outside the patch come from global memory)
             const bool inp = pa_ >= 1 && pa_ < DYN_PATCH - 1 && pb_ >= 1 && pb_ < DYN_PATCH - 1;
             const float top0 = inp ? X.s_patch[(pa_ * DYN_PATCH + pb_) * 64] : hf_at(T, ix, iy);
             const v3 vpt = s6lin(B.vel) + cross(s6ang(B.vel), x);
@@ -375,9 +378,9 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
                 const float top = nb == 4 ? top0 : (inp ? X.s_patch[((pa_ + ox_) * DYN_PATCH + pb_ + oy_) * 64] : hf_at(T, ix + ox_, iy + oy_));
                 if (!(nb == 4 || top > top0 + 1e-3f) || zlo > top) continue;
                 v3 n;
-                const float pen = nb == 4 ? own_column_contact(T, g, rad, ix, iy, top0, [&](int ox, int oy) {
+                const float pen = nb == 4 ? own_column_contact(Tp, g, rad, pa_, pb_, top0, [&](int ox, int oy) {
                                                 return inp ? X.s_patch[((pa_ + ox) * DYN_PATCH + pb_ + oy) * 64] : hf_at(T, ix + ox, iy + oy); }, n)
-                                          : sphere_vs_column(T, g, rad, ix + ox_, iy + oy_, top, n);
+                                          : sphere_vs_column(Tp, g, rad, pa_ + ox_, pb_ + oy_, top, n);
                 if (pen > 0.f) wv_contact_generic(M, dt, x, vpt, pen, n, IA, pA, fsum);
             }
         }
@@ -546,7 +549,7 @@ __device__ __forceinline__ void wv_store_joint(const DynModel &M, int b, const W
 
 __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__restrict__ Mp, const WaveTables *__restrict__ Wp, DynTerrain T,
                                                           ParcEnvBuffers buf, const float *__restrict__ action,
-                                                          const float *__restrict__ env_off_all, int N) {
+                                                          const float *__restrict__ env_off_all, float *__restrict__ root_shadow, int N) {
     extern __shared__ float smem[];
     const DynModel &M = *Mp;
     const WaveTables &W = *Wp;
@@ -575,7 +578,7 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
         if (k < llen) wv_load_joint(M, W.body[lc][k], limb[k], dp, dv, ac);
         if (k < tlen) wv_load_joint(M, W.body[0][k], trunk[k], dp, dv, ac);
     }
-    v3 rp = mk(buf.char_root_pos[3 * ec], buf.char_root_pos[3 * ec + 1], buf.char_root_pos[3 * ec + 2]);
+    const v3 rp_buf = mk(buf.char_root_pos[3 * ec], buf.char_root_pos[3 * ec + 1], buf.char_root_pos[3 * ec + 2]);
     q4 rq; rq.x = buf.char_root_rot[4 * ec]; rq.y = buf.char_root_rot[4 * ec + 1]; rq.z = buf.char_root_rot[4 * ec + 2]; rq.w = buf.char_root_rot[4 * ec + 3];
     rq = qnormalize(rq);
     v3 rv = mk(buf.char_root_vel[3 * ec], buf.char_root_vel[3 * ec + 1], buf.char_root_vel[3 * ec + 2]);
@@ -583,9 +586,26 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
 
     WvCtx X;
     X.s_patch = s_patch; X.s_pmax = s_pmax; X.s_pmax3 = s_pmax3; X.dt = dt;
-    X.eo0 = env_off_all[3 * ec]; X.eo1 = env_off_all[3 * ec + 1]; X.eo2 = env_off_all[3 * ec + 2];
+    const float eo0 = env_off_all[3 * ec], eo1 = env_off_all[3 * ec + 1], eo2 = env_off_all[3 * ec + 2];
     X.cell_min = fminf(T.dx, T.dy);
-    X.pox = cell_of(rp.x + X.eo0, T.min_x, T.dx) - DYN_PATCH / 2; X.poy = cell_of(rp.y + X.eo1, T.min_y, T.dy) - DYN_PATCH / 2;
+    X.pox = cell_of(rp_buf.x + eo0, T.min_x, T.dx) - DYN_PATCH / 2; X.poy = cell_of(rp_buf.y + eo1, T.min_y, T.dy) - DYN_PATCH / 2;
+    X.Tp = T; X.Tp.hf = nullptr; X.Tp.min_x = -(float)(DYN_PATCH / 2) * T.dx; X.Tp.min_y = -(float)(DYN_PATCH / 2) * T.dy;
+    // PRECISION.  The state buffers hold the root in the reference's env-local frame (ig_parkour_env.py:386-398), whose
+    // coordinates reach ~1 km at 65 536 envs: one ulp is 6e-5 m there, so `x += dt v` at dt = 1/120 s would drop every
+    // |v| < 7 mm/s of a far env.  The step therefore runs in the patch frame, whose origin is the centre of the root's cell:
+    //   anc   = that centre in env-local coordinates (any nearby representable value serves: it is fixed for the step);
+    //   rp    = (buffer - anc) + residual: the subtraction of two neighbours is exact; the residual is what the last
+    //           step's write-back rounded away (kept in library memory, valid while the buffer still holds what that step
+    //           wrote, i.e. unless the caller reset or edited the state);
+    //   out   = fl(anc + rp) goes back to the buffer, rp - (out - anc) becomes the new residual.
+    // The observation / reward path keeps reading the reference-format buffer (bit-for-bit the reference's quantisation).
+    const v3 anc = mk((T.min_x + (float)(X.pox + DYN_PATCH / 2) * T.dx) - eo0, (T.min_y + (float)(X.poy + DYN_PATCH / 2) * T.dy) - eo1, -eo2);
+    v3 rlo = mk(0.f, 0.f, 0.f);
+    if (root_shadow) {
+        const float *sh = root_shadow + 6 * (size_t)ec;
+        if (sh[0] == rp_buf.x && sh[1] == rp_buf.y && sh[2] == rp_buf.z) rlo = mk(sh[3], sh[4], sh[5]);
+    }
+    v3 rp = mk((rp_buf.x - anc.x) + rlo.x, (rp_buf.y - anc.y) + rlo.y, (rp_buf.z - anc.z) + rlo.z);
     // local height patch of each env (the 4 waves share the 81 cells), then its 3x3 and 5x5 running maxima
     for (int i = w; i < DYN_PATCH * DYN_PATCH; i += 4) s_patch[i * 64] = hf_at(T, X.pox + i / DYN_PATCH, X.poy + i % DYN_PATCH);
     __syncthreads();
@@ -824,7 +844,13 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
     if (!env_ok) return;
     float *odp = buf.char_dof_pos + (size_t)D_ * e, *odv = buf.char_dof_vel + (size_t)D_ * e, *ocf = buf.contact_forces + 3 * (size_t)e * B_;
     if (w == 0) {
-        float *o = buf.char_root_pos + 3 * (size_t)e; o[0] = rp.x; o[1] = rp.y; o[2] = rp.z;
+        const v3 out = mk(anc.x + rp.x, anc.y + rp.y, anc.z + rp.z);
+        float *o = buf.char_root_pos + 3 * (size_t)e; o[0] = out.x; o[1] = out.y; o[2] = out.z;
+        if (root_shadow) {
+            float *sh = root_shadow + 6 * (size_t)e;
+            sh[0] = out.x; sh[1] = out.y; sh[2] = out.z;
+            sh[3] = rp.x - (out.x - anc.x); sh[4] = rp.y - (out.y - anc.y); sh[5] = rp.z - (out.z - anc.z);
+        }
         o = buf.char_root_rot + 4 * (size_t)e; o[0] = rq.x; o[1] = rq.y; o[2] = rq.z; o[3] = rq.w;
         o = buf.char_root_vel + 3 * (size_t)e; o[0] = rv.x; o[1] = rv.y; o[2] = rv.z;
         o = buf.char_root_ang_vel + 3 * (size_t)e; o[0] = rw.x; o[1] = rw.y; o[2] = rw.z;

@@ -1204,6 +1204,7 @@ struct ParcEnv {
     bool bound = false, have_motions = false, have_terrain = false;
     StepParams sp;
     float4 *d_prep = nullptr;
+    float *d_root_shadow = nullptr;   // [N][6]: root position the dynamics last wrote + what that write rounded away (k_dynamics_wave)
     parcdyn::DynModel h_dyn;
     parcdyn::DynModel *d_dyn = nullptr;
     parcdyn::CoopTables h_coop;
@@ -1246,7 +1247,7 @@ extern "C" const char *parc_last_error(void) { return g_err.c_str(); }
 extern "C" int parc_abi_version(void) { return PARC_ABI_VERSION; }
 
 static void free_dev(ParcEnv *e) {
-    void *ptrs[] = {e->d_prep, e->d_dyn, e->d_coop, e->d_wave, e->d_tab, e->d_ray, e->d_env_off, e->d_hf, e->d_motion_off, e->d_records, e->d_meta, e->d_weights, e->d_fail,
+    void *ptrs[] = {e->d_root_shadow, e->d_prep, e->d_dyn, e->d_coop, e->d_wave, e->d_tab, e->d_ray, e->d_env_off, e->d_hf, e->d_motion_off, e->d_records, e->d_meta, e->d_weights, e->d_fail,
                     e->d_cdf, e->d_ema, e->d_done_list, e->d_done_key, e->d_chunk_count, e->d_motion_done, e->d_reset_count, e->d_reset_calls, e->d_tmp_mid, e->d_tmp_tid, e->d_tmp_t0, e->d_tmp_noise,
                     e->d_scratch_jr};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -1380,6 +1381,10 @@ extern "C" int parc_env_create(const ParcEnvConfig *cfg, ParcEnv **out) {
         e->use_coop = coop_ok && !e->use_wave && want != "thread";
         if (e->use_wave) {
             r = up((void **)&e->d_wave, &e->h_wave, sizeof(e->h_wave));
+            if (r == hipSuccess && !getenv("PARC_DYN_NO_RESIDUAL")) { // (developer switch: the precision test measures the drift without it)
+                r = hipMalloc((void **)&e->d_root_shadow, sizeof(float) * 6 * N);
+                if (r == hipSuccess) r = hipMemset(e->d_root_shadow, 0xff, sizeof(float) * 6 * N); // NaN: matches no buffer value
+            }
             if (r == hipSuccess)
                 r = hipFuncSetAttribute((const void *)parcdyn::k_dynamics_wave, hipFuncAttributeMaxDynamicSharedMemorySize, parcdyn::wv_lds_floats(e->h_wave.fac_total) * (int)sizeof(float));
         } else if (e->use_coop) {
@@ -1553,7 +1558,7 @@ static int launch_dynamics(ParcEnv *e, const float *action_dev, hipStream_t st) 
     if (e->use_wave)
         hipLaunchKernelGGL(parcdyn::k_dynamics_wave, dim3((e->N + 63) / 64), dim3(256), parcdyn::wv_lds_floats(e->h_wave.fac_total) * sizeof(float), st,
                            (const parcdyn::DynModel *)e->d_dyn, (const parcdyn::WaveTables *)e->d_wave, T, e->sp.buf, action_dev,
-                           (const float *)e->d_env_off, e->N);
+                           (const float *)e->d_env_off, e->d_root_shadow, e->N);
     else if (e->use_coop)
         hipLaunchKernelGGL(parcdyn::k_dynamics_coop, dim3((e->N + CO_ENVS - 1) / CO_ENVS), dim3(64), 0, st, (const parcdyn::DynModel *)e->d_dyn,
                            (const parcdyn::CoopTables *)e->d_coop, T, e->sp.buf, action_dev, (const float *)e->d_env_off, e->N);
