@@ -38,7 +38,8 @@ struct WaveTables {
     int body[1 + WV_MAXLIMB][WV_MAXLEN];
     int par_slot[1 + WV_MAXLIMB];          // attach slot of the trunk body a limb hangs off
     int early[1 + WV_MAXLIMB];             // limb hangs off a non-root trunk body: finished before the trunk's upper part starts
-    int helper;                            // wave (>= 1) of an early limb: idle in part B, it prepares the root body's own inertia + contacts; -1 if none
+    int helper;                            // wave (>= 1) of an early limb: idle in part B, it prepares own inertia + contacts of trunk bodies; -1 if none
+    int prep[WV_MAXLEN];                   // per trunk position: 1 = prepared by the helper wave (positions 0 and 1 that carry limbs)
     int att_slot[WV_MAXLEN];               // per trunk position: attach slot or -1
     int nchild[WV_MAXLEN];                 // per trunk position: limbs hanging off it
     int child[WV_MAXLEN][WV_MAXLIMB];      // limb chain ids (1..)
@@ -59,7 +60,8 @@ struct WaveTables {
 #define WV_OFF_PMAX (WV_OFF_PATCH + DYN_PATCH * DYN_PATCH * 64)
 #define WV_OFF_PMAX3 (WV_OFF_PMAX + WV_PI * WV_PI * 64)
 #define WV_OFF_ROOTI (WV_OFF_PMAX3 + WV_P3 * WV_P3 * 64)
-#define WV_OFF_FAC (WV_OFF_ROOTI + 30 * 64)
+#define WV_OFF_FLAG (WV_OFF_ROOTI + 2 * 30 * 64)   // one word: "the helper has published trunk position 1 for substep n"
+#define WV_OFF_FAC (WV_OFF_FLAG + 64)
 #define WV_LDS_FLOATS_MAX (WV_OFF_FAC + (1 + WV_MAXLIMB) * WV_MAXLEN * WV_FAC * 64)
 inline int wv_lds_floats(int fac_total) { return WV_OFF_FAC + fac_total * 64; } // the factor region is last and packed
 
@@ -103,6 +105,7 @@ inline bool build_wave_tables(const DynModel &M, const CoopTables &C, WaveTables
     }
     W.helper = -1;
     for (int c = 2; c < C.nchain; ++c) if (W.early[c] && W.att_slot[0] >= 0) { W.helper = c - 1; break; }
+    for (int k = 0; k < 2 && k < W.len[0]; ++k) W.prep[k] = (W.helper >= 0 && W.att_slot[k] >= 0) ? 1 : 0;
     int off = 0;
     for (int c = 0; c < C.nchain; ++c)
         for (int k = 0; k < W.len[c]; ++k) {
@@ -178,6 +181,10 @@ __device__ __forceinline__ void wv_fk_body(const DynModel &M, int b, WvBody &B, 
 
 #ifndef WV_PASS1_UNROLL
 #define WV_PASS1_UNROLL _Pragma("unroll 4")
+#endif
+
+#ifndef WV_EXTRA_ATTR
+#define WV_EXTRA_ATTR
 #endif
 
 struct WvCtx { // per-lane constants of the control step
@@ -284,23 +291,39 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
     unsigned hit = 0u;
     bool slow = false;
     if (__any(hmax > -1.0e38f)) {
-        auto cull_point = [&](int pi, bool valid) __attribute__((always_inline)) {
-            const int kp = pt0 + (valid ? pi : 0);
-            const v3 x = r + mulv(R, mk(M.col_pos[kp][0], M.col_pos[kp][1], M.col_pos[kp][2]));
-            const v3 g = x + rootp;
-            const float rad = M.col_r[kp];
-            const float zlo = g.z - rad;
-            const int pa_ = cell_of(g.x, Tp.min_x, Tp.dx), pb_ = cell_of(g.y, Tp.min_y, Tp.dy);
-            const bool inp = pa_ >= 1 && pa_ < DYN_PATCH - 1 && pb_ >= 1 && pb_ < DYN_PATCH - 1;
-            const bool fast = inp && rad + 2e-3f < X.cell_min * 0.5f;
-            const int pac = pa_ < 1 ? 1 : (pa_ > DYN_PATCH - 2 ? DYN_PATCH - 2 : pa_), pbc = pb_ < 1 ? 1 : (pb_ > DYN_PATCH - 2 ? DYN_PATCH - 2 : pb_);
-            float m3 = X.s_pmax3[((pac - 1) * WV_P3 + pbc - 1) * 64];
-            asm volatile("" : "+v"(m3)); // the look-up is issued unconditionally (clamped address): nothing to branch around
-            const bool low = valid && !(zlo > hmax);
-            hit |= ((fast && low && !(zlo > m3)) ? 1u : 0u) << pi;
-            slow = slow || (low && !fast);
+        // two points per iteration; the table entries of the NEXT pair are requested at the top of the iteration (they sit in
+        // SGPRs by the time they are used) and both look-ups of this pair are in flight together: one exposed wait per pair
+        struct ColPt { float x, y, z, r; };
+        auto load_pt = [&](int pi) __attribute__((always_inline)) {
+            const int kp = pt0 + (pi < npt ? pi : 0);
+            ColPt c; c.x = M.col_pos[kp][0]; c.y = M.col_pos[kp][1]; c.z = M.col_pos[kp][2]; c.r = M.col_r[kp];
+            return c;
         };
-        for (int pi = 0; pi < npt; pi += 2) { cull_point(pi, true); cull_point(pi + 1, pi + 1 < npt); }
+        const float fast_r = X.cell_min * 0.5f - 2e-3f;
+        ColPt c0 = load_pt(0), c1 = load_pt(1);
+        for (int pi = 0; pi < npt; pi += 2) {
+            const ColPt n0 = load_pt(pi + 2), n1 = load_pt(pi + 3);
+            float zlo[2]; int addr[2]; bool inp[2];
+            PARC_UNROLL
+            for (int q = 0; q < 2; ++q) {
+                const ColPt &c = q == 0 ? c0 : c1;
+                const v3 g = r + mulv(R, mk(c.x, c.y, c.z)) + rootp;
+                zlo[q] = g.z - c.r;
+                const int pa_ = cell_of(g.x, Tp.min_x, Tp.dx), pb_ = cell_of(g.y, Tp.min_y, Tp.dy);
+                inp[q] = pa_ >= 1 && pa_ < DYN_PATCH - 1 && pb_ >= 1 && pb_ < DYN_PATCH - 1;
+                const int pac = pa_ < 1 ? 1 : (pa_ > DYN_PATCH - 2 ? DYN_PATCH - 2 : pa_), pbc = pb_ < 1 ? 1 : (pb_ > DYN_PATCH - 2 ? DYN_PATCH - 2 : pb_);
+                addr[q] = ((pac - 1) * WV_P3 + pbc - 1) * 64;
+            }
+            float m3a = X.s_pmax3[addr[0]], m3b = X.s_pmax3[addr[1]];
+            asm volatile("" : "+v"(m3a), "+v"(m3b)); // both look-ups are issued unconditionally (clamped addresses), back to back
+            const bool v1 = pi + 1 < npt;
+            const bool fast0 = inp[0] && c0.r < fast_r, fast1 = inp[1] && c1.r < fast_r;
+            const bool low0 = !(zlo[0] > hmax), low1 = v1 && !(zlo[1] > hmax);
+            hit |= ((fast0 && low0 && !(zlo[0] > m3a)) ? 1u : 0u) << pi;
+            hit |= ((fast1 && low1 && !(zlo[1] > m3b)) ? 2u : 0u) << pi;
+            slow = slow || (low0 && !fast0) || (low1 && !fast1);
+            c0 = n0; c1 = n1;
+        }
     }
 #ifdef WV_EXP_NOSLOW
     slow = false;
@@ -321,6 +344,9 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
     }
 #endif
     if (slow) hit = 0u;
+#ifdef WV_EXP_NOPASS2
+    hit = 0u;
+#endif
     for (int pi = 0; pi < npt; ++pi) {
         const bool mine = (hit >> pi) & 1u;
         if (!__any(mine)) continue; // uniform
@@ -344,7 +370,11 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
             }
             const float ex = g.x - (Tp.min_x + (float)pa_ * Tp.dx), ey = g.y - (Tp.min_y + (float)pb_ * Tp.dy);
             const float lim = rad + 1e-3f; // slack >> the rounding of the cell centres: it only admits candidates
+#ifdef WV_EXP_NONEIGH
+            const bool nx = false, ny = false;
+#else
             const bool nx = hx - fabsf(ex) < lim, ny = hy - fabsf(ey) < lim;
+#endif
             if (nx || ny) {
                 const int sx = ex >= 0.f ? 1 : -1, sy = ey >= 0.f ? 1 : -1;
                 for (int c = 0; c < 3; ++c) { // x side, y side, diagonal
@@ -547,7 +577,7 @@ __device__ __forceinline__ void wv_store_joint(const DynModel &M, int b, const W
     cf[3 * b] = fc.x; cf[3 * b + 1] = fc.y; cf[3 * b + 2] = fc.z;
 }
 
-__global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__restrict__ Mp, const WaveTables *__restrict__ Wp, DynTerrain T,
+__global__ __launch_bounds__(256, 1) WV_EXTRA_ATTR void k_dynamics_wave(const DynModel *__restrict__ Mp, const WaveTables *__restrict__ Wp, DynTerrain T,
                                                           ParcEnvBuffers buf, const float *__restrict__ action,
                                                           const float *__restrict__ env_off_all, float *__restrict__ root_shadow, int N) {
     extern __shared__ float smem[];
@@ -570,6 +600,8 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
     float *s_attkin = smem + WV_OFF_ATTKIN + lane, *s_up = smem + WV_OFF_UP + lane, *s_attacc = smem + WV_OFF_ATTACC + lane;
     float *s_rootp = smem + WV_OFF_ROOTP + lane, *s_patch = smem + WV_OFF_PATCH + lane, *s_pmax = smem + WV_OFF_PMAX + lane;
     float *s_fac = smem + WV_OFF_FAC + lane, *s_rooti = smem + WV_OFF_ROOTI + lane, *s_pmax3 = smem + WV_OFF_PMAX3 + lane;
+    volatile int *s_flag = reinterpret_cast<volatile int *>(smem + WV_OFF_FLAG);
+    if (threadIdx.x == 0) *s_flag = 0; // published before the first barrier below
 
     const float *dp = buf.char_dof_pos + (size_t)D_ * ec, *dv = buf.char_dof_vel + (size_t)D_ * ec, *ac = action + (size_t)D_ * ec;
     WvBody limb[WV_MAXLEN], trunk[WV_MAXLEN];
@@ -606,25 +638,55 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
         if (sh[0] == rp_buf.x && sh[1] == rp_buf.y && sh[2] == rp_buf.z) rlo = mk(sh[3], sh[4], sh[5]);
     }
     v3 rp = mk((rp_buf.x - anc.x) + rlo.x, (rp_buf.y - anc.y) + rlo.y, (rp_buf.z - anc.z) + rlo.z);
-    // local height patch of each env (the 4 waves share the 81 cells), then its 3x3 and 5x5 running maxima
-    for (int i = w; i < DYN_PATCH * DYN_PATCH; i += 4) s_patch[i * 64] = hf_at(T, X.pox + i / DYN_PATCH, X.poy + i % DYN_PATCH);
-    __syncthreads();
-    for (int i = w; i < WV_P3 * WV_P3; i += 4) {
-        const int pi_ = i / WV_P3 + 1, pj_ = i % WV_P3 + 1;
-        float m = -3.0e38f;
+    // local height patch of each env (the 4 waves share the 81 cells), then its 3x3 and 5x5 running maxima.  The loops are
+    // fully unrolled with a uniform predicate so that all loads of a pass are in flight together (one resident wave per
+    // SIMD: a load per iteration would expose its whole latency 20 times).
+    {
+        constexpr int NP = (DYN_PATCH * DYN_PATCH + 3) / 4;
+        float hv[NP];
         PARC_UNROLL
-        for (int a = -1; a <= 1; ++a) {
-            PARC_UNROLL
-            for (int q = -1; q <= 1; ++q) m = fmaxf(m, s_patch[((pi_ + a) * DYN_PATCH + pj_ + q) * 64]);
+        for (int it = 0; it < NP; ++it) {
+            const int i = w + 4 * it;
+            hv[it] = i < DYN_PATCH * DYN_PATCH ? hf_at(T, X.pox + i / DYN_PATCH, X.poy + i % DYN_PATCH) : 0.f;
         }
-        s_pmax3[i * 64] = m;
+        PARC_UNROLL
+        for (int it = 0; it < NP; ++it) {
+            const int i = w + 4 * it;
+            if (i < DYN_PATCH * DYN_PATCH) s_patch[i * 64] = hv[it];
+        }
     }
     __syncthreads();
-    for (int i = w; i < WV_PI * WV_PI; i += 4) { // 5x5 window = the four 3x3 windows at the diagonal offsets
-        const int pi_ = i / WV_PI + 1, pj_ = i % WV_PI + 1; // centre (pi_+1, pj_+1) in patch cells = (pi_, pj_) in the 3x3 table
-        const float m = fmaxf(fmaxf(s_pmax3[((pi_ - 1) * WV_P3 + pj_ - 1) * 64], s_pmax3[((pi_ - 1) * WV_P3 + pj_ + 1) * 64]),
-                              fmaxf(s_pmax3[((pi_ + 1) * WV_P3 + pj_ - 1) * 64], s_pmax3[((pi_ + 1) * WV_P3 + pj_ + 1) * 64]));
-        s_pmax[i * 64] = m;
+    {
+        constexpr int N3 = (WV_P3 * WV_P3 + 3) / 4;
+        float mv[N3];
+        PARC_UNROLL
+        for (int it = 0; it < N3; ++it) {
+            const int i = w + 4 * it < WV_P3 * WV_P3 ? w + 4 * it : 0;
+            const int pi_ = i / WV_P3 + 1, pj_ = i % WV_P3 + 1;
+            float m = -3.0e38f;
+            PARC_UNROLL
+            for (int a = -1; a <= 1; ++a) {
+                PARC_UNROLL
+                for (int q = -1; q <= 1; ++q) m = fmaxf(m, s_patch[((pi_ + a) * DYN_PATCH + pj_ + q) * 64]);
+            }
+            mv[it] = m;
+        }
+        PARC_UNROLL
+        for (int it = 0; it < N3; ++it) if (w + 4 * it < WV_P3 * WV_P3) s_pmax3[(w + 4 * it) * 64] = mv[it];
+    }
+    __syncthreads();
+    {
+        constexpr int N5 = (WV_PI * WV_PI + 3) / 4;
+        float mv[N5];
+        PARC_UNROLL
+        for (int it = 0; it < N5; ++it) { // 5x5 window = the four 3x3 windows at the diagonal offsets
+            const int i = w + 4 * it < WV_PI * WV_PI ? w + 4 * it : 0;
+            const int pi_ = i / WV_PI + 1, pj_ = i % WV_PI + 1; // centre (pi_+1, pj_+1) in patch cells = (pi_, pj_) in the 3x3 table
+            mv[it] = fmaxf(fmaxf(s_pmax3[((pi_ - 1) * WV_P3 + pj_ - 1) * 64], s_pmax3[((pi_ - 1) * WV_P3 + pj_ + 1) * 64]),
+                           fmaxf(s_pmax3[((pi_ + 1) * WV_P3 + pj_ - 1) * 64], s_pmax3[((pi_ + 1) * WV_P3 + pj_ + 1) * 64]));
+        }
+        PARC_UNROLL
+        for (int it = 0; it < N5; ++it) if (w + 4 * it < WV_PI * WV_PI) s_pmax[(w + 4 * it) * 64] = mv[it];
     }
     __syncthreads();
 
@@ -703,12 +765,17 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
             const int b = W.body[0][k];
             const m3 R = qmat(trunk[k].bq);
             sym6 IA = Ict; s6 pA = pct;
-            if (k == 0 && W.helper >= 0) { // prepared by the helper wave during part B
+            if (W.prep[k]) { // prepared by the helper wave during part B
+                if (k > 0) { // the root's record is covered by the barrier before phase 3; position 1 is published through the flag
+                    while (*s_flag < sub + 1) __builtin_amdgcn_s_sleep(4);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                }
+                const float *sr = s_rooti + k * 30 * 64;
                 PARC_UNROLL
-                for (int i = 0; i < 21; ++i) IA.s[i] += s_rooti[i * 64];
+                for (int i = 0; i < 21; ++i) IA.s[i] += sr[i * 64];
                 PARC_UNROLL
-                for (int a = 0; a < 6; ++a) pA.a[a] += s_rooti[(21 + a) * 64];
-                trunk[k].fcon = mk(s_rooti[27 * 64], s_rooti[28 * 64], s_rooti[29 * 64]);
+                for (int a = 0; a < 6; ++a) pA.a[a] += sr[(21 + a) * 64];
+                trunk[k].fcon = mk(sr[27 * 64], sr[28 * 64], sr[29 * 64]);
             } else {
                 WSTAMP(15);
                 wv_body_inertia(M, W, T, X, b, trunk[k], R, rootp, IA, pA WSTAMP_ARGS);
@@ -764,23 +831,33 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
             PARC_UNROLL
             for (int k = WV_MAXLEN - 1; k >= 1; --k) if (k < tlen) trunk_body(k);
         }
-        if (w == W.helper) { // part B, helper: own inertia + contacts of the trunk's root body (its kinematics are in the attach slot)
-            const float *s = s_attkin + W.att_slot[0] * 13 * 64;
-            WvBody rb;
-            rb.bq.x = s[0]; rb.bq.y = s[64]; rb.bq.z = s[128]; rb.bq.w = s[192];
-            rb.r = mk(s[256], s[320], s[384]);
+        if (w == W.helper) { // part B, helper: own inertia + contacts of the trunk bodies that carry limbs (their kinematics are in the
+                             // attach slots).  Position 1 first: wave 0 needs it as soon as it is through with the bodies above.
             PARC_UNROLL
-            for (int a = 0; a < 6; ++a) rb.vel.a[a] = s[(7 + a) * 64];
-            sym6 IA; s6 pA = s6zero();
-            PARC_UNROLL
-            for (int i = 0; i < 21; ++i) IA.s[i] = 0.f;
-            WSTAMP(15);
-            wv_body_inertia(M, W, T, X, W.body[0][0], rb, qmat(rb.bq), rootp, IA, pA WSTAMP_ARGS);
-            PARC_UNROLL
-            for (int i = 0; i < 21; ++i) s_rooti[i * 64] = IA.s[i];
-            PARC_UNROLL
-            for (int a = 0; a < 6; ++a) s_rooti[(21 + a) * 64] = pA.a[a];
-            s_rooti[27 * 64] = rb.fcon.x; s_rooti[28 * 64] = rb.fcon.y; s_rooti[29 * 64] = rb.fcon.z;
+            for (int k = 1; k >= 0; --k) {
+                if (!W.prep[k]) continue;
+                const float *s = s_attkin + W.att_slot[k] * 13 * 64;
+                WvBody rb;
+                rb.bq.x = s[0]; rb.bq.y = s[64]; rb.bq.z = s[128]; rb.bq.w = s[192];
+                rb.r = mk(s[256], s[320], s[384]);
+                PARC_UNROLL
+                for (int a = 0; a < 6; ++a) rb.vel.a[a] = s[(7 + a) * 64];
+                sym6 IA; s6 pA = s6zero();
+                PARC_UNROLL
+                for (int i = 0; i < 21; ++i) IA.s[i] = 0.f;
+                WSTAMP(15);
+                wv_body_inertia(M, W, T, X, W.body[0][k], rb, qmat(rb.bq), rootp, IA, pA WSTAMP_ARGS);
+                float *sr = s_rooti + k * 30 * 64;
+                PARC_UNROLL
+                for (int i = 0; i < 21; ++i) sr[i * 64] = IA.s[i];
+                PARC_UNROLL
+                for (int a = 0; a < 6; ++a) sr[(21 + a) * 64] = pA.a[a];
+                sr[27 * 64] = rb.fcon.x; sr[28 * 64] = rb.fcon.y; sr[29 * 64] = rb.fcon.z;
+                if (k > 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // LDS writes of this wave complete in order; this keeps the compiler in line
+                    if (lane == 0) *s_flag = sub + 1;
+                }
+            }
         }
         if (has_limb && !early && llen > 1) { // part B, late limbs: the rest of the chain
             PARC_UNROLL
