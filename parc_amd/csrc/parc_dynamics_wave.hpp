@@ -32,7 +32,24 @@ namespace parcdyn {
 #define WV_P3 (DYN_PATCH - 2)  // cells that have a full 3x3 neighbourhood inside the patch
 #define WV_FAC 21     // K (18) + D^-1 u (3); a hinge uses slots 0..5 (K) and 6 (D^-1 u)
 
+// Everything the wave kernel reads about a body, contiguous (256 B): the body index is wave-uniform but dynamic, so every
+// field access is a scalar load; one record per body turns ~15 separate s_load + s_waitcnt round trips per body and pass
+// (one per DynModel array) into a few wide loads from one base address.
+struct WvBodyC {
+    int jtype, dof_idx, npt, pt0;
+    float lt[3], mass;
+    float lr[4];
+    float axis[3], brho;
+    float com[3], pad0;
+    float inertia[6], pad1[2];
+    float bc[3], pad2;
+    float kp[3], kd[3], arm[3], eff[3], lo[3], hi[3], act_lo[3], act_hi[3]; // the joint's dofs (hinge: [0])
+    float pad3[8];
+};
+
 struct WaveTables {
+    WvBodyC c[DYN_MAXB];
+    float colp[DYN_MAXC][4];               // collision point: body-frame position, radius
     int nlimb;
     int len[1 + WV_MAXLIMB];               // chain 0 = trunk, 1.. = limbs
     int body[1 + WV_MAXLIMB][WV_MAXLEN];
@@ -114,6 +131,21 @@ inline bool build_wave_tables(const DynModel &M, const CoopTables &C, WaveTables
             off += (b == 0) ? 0 : (jt == DJ_SPHERICAL ? WV_FAC : (jt == DJ_HINGE ? 7 : 0));
         }
     W.fac_total = off;
+    for (int b = 0; b < M.B; ++b) {
+        WvBodyC &c = W.c[b];
+        c.jtype = M.jtype[b]; c.dof_idx = M.dof_idx[b]; c.npt = W.npt[b]; c.pt0 = W.pt0[b];
+        c.mass = M.mass[b]; c.brho = W.brho[b];
+        for (int a = 0; a < 3; ++a) { c.lt[a] = M.lt[b][a]; c.axis[a] = M.axis[b][a]; c.com[a] = M.com[b][a]; c.bc[a] = W.bc[b][a]; }
+        for (int a = 0; a < 4; ++a) c.lr[a] = M.lr[b][a];
+        for (int a = 0; a < 6; ++a) c.inertia[a] = M.inertia[b][a];
+        const int nd = b == 0 ? 0 : (M.jtype[b] == DJ_SPHERICAL ? 3 : (M.jtype[b] == DJ_HINGE ? 1 : 0));
+        for (int q = 0; q < nd; ++q) {
+            const int d = M.dof_idx[b] + q;
+            c.kp[q] = M.kp[d]; c.kd[q] = M.kd[d]; c.arm[q] = M.arm[d]; c.eff[q] = M.eff[d]; c.lo[q] = M.lo[d]; c.hi[q] = M.hi[d];
+            c.act_lo[q] = M.act_lo[d]; c.act_hi[q] = M.act_hi[d];
+        }
+    }
+    for (int k = 0; k < M.ncol; ++k) { for (int a = 0; a < 3; ++a) W.colp[k][a] = M.col_pos[k][a]; W.colp[k][3] = M.col_r[k]; }
     if (wv_lds_floats(off) * (int)sizeof(float) > 160 * 1024) return false; // does not fit one CU's LDS: the caller falls back to the chain-parallel kernel
     return true;
 }
@@ -143,35 +175,35 @@ struct WvBody { // per-body registers of the owning lane
     v3 fcon, qdd;
 };
 
-__device__ __forceinline__ void wv_load_joint(const DynModel &M, int b, WvBody &B, const float *dp, const float *dv, const float *ac) {
+__device__ __forceinline__ void wv_load_joint(const DynModel &M, const WaveTables &W, int b, WvBody &B, const float *dp, const float *dv, const float *ac) {
     B.jq.x = 0.f; B.jq.y = 0.f; B.jq.z = 0.f; B.jq.w = 1.f; B.tq = B.jq; B.hang = 0.f; B.thang = 0.f; B.qd = mk(0.f, 0.f, 0.f);
     B.fcon = mk(0.f, 0.f, 0.f); B.qdd = mk(0.f, 0.f, 0.f);
-    const int jt = M.jtype[b], di = M.dof_idx[b];
+    const int jt = W.c[b].jtype, di = W.c[b].dof_idx;
     if (jt == DJ_SPHERICAL) {
         B.jq = qexp(mk(dp[di], dp[di + 1], dp[di + 2]));
-        B.tq = qexp(mk(clampf(ac[di], M.act_lo[di], M.act_hi[di]), clampf(ac[di + 1], M.act_lo[di + 1], M.act_hi[di + 1]),
-                       clampf(ac[di + 2], M.act_lo[di + 2], M.act_hi[di + 2])));
+        B.tq = qexp(mk(clampf(ac[di], W.c[b].act_lo[0], W.c[b].act_hi[0]), clampf(ac[di + 1], W.c[b].act_lo[1], W.c[b].act_hi[1]),
+                       clampf(ac[di + 2], W.c[b].act_lo[2], W.c[b].act_hi[2])));
         B.qd = mk(dv[di], dv[di + 1], dv[di + 2]);
     } else if (jt == DJ_HINGE) {
-        B.hang = dp[di]; B.thang = clampf(ac[di], M.act_lo[di], M.act_hi[di]); B.qd.x = dv[di];
+        B.hang = dp[di]; B.thang = clampf(ac[di], W.c[b].act_lo[0], W.c[b].act_hi[0]); B.qd.x = dv[di];
     }
 }
 
 // kinematics of body b given its parent's (pq, pr, pv); leaves its own in (pq, pr, pv) for the next body of the chain
-__device__ __forceinline__ void wv_fk_body(const DynModel &M, int b, WvBody &B, q4 &pq, v3 &pr, s6 &pv) {
+__device__ __forceinline__ void wv_fk_body(const DynModel &M, const WaveTables &W, int b, WvBody &B, q4 &pq, v3 &pr, s6 &pv) {
     s6 cJ = s6zero();
     if (b != 0) {
-        const int jt = M.jtype[b];
+        const int jt = W.c[b].jtype;
         const m3 Rp = qmat(pq);
-        pr = pr + mulv(Rp, mk(M.lt[b][0], M.lt[b][1], M.lt[b][2]));
-        q4 lq; lq.x = M.lr[b][0]; lq.y = M.lr[b][1]; lq.z = M.lr[b][2]; lq.w = M.lr[b][3];
+        pr = pr + mulv(Rp, mk(W.c[b].lt[0], W.c[b].lt[1], W.c[b].lt[2]));
+        q4 lq; lq.x = W.c[b].lr[0]; lq.y = W.c[b].lr[1]; lq.z = W.c[b].lr[2]; lq.w = W.c[b].lr[3];
         q4 jr = B.jq;
-        if (jt == DJ_HINGE) jr = qexp(B.hang * mk(M.axis[b][0], M.axis[b][1], M.axis[b][2]));
+        if (jt == DJ_HINGE) jr = qexp(B.hang * mk(W.c[b].axis[0], W.c[b].axis[1], W.c[b].axis[2]));
         pq = qnormalize(qmul(pq, qmul(lq, jr)));
         const m3 R = qmat(pq);
         v3 wj = mk(0.f, 0.f, 0.f);
         if (jt == DJ_SPHERICAL) wj = mulv(R, B.qd);
-        else if (jt == DJ_HINGE) wj = B.qd.x * mulv(R, mk(M.axis[b][0], M.axis[b][1], M.axis[b][2]));
+        else if (jt == DJ_HINGE) wj = B.qd.x * mulv(R, mk(W.c[b].axis[0], W.c[b].axis[1], W.c[b].axis[2]));
         const s6 vJ = s6mk(wj, cross(pr, wj));
         pv = pv + vJ;
         cJ = crm(pv, vJ);
@@ -229,9 +261,9 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
     const float dt = X.dt;
     const DynTerrain &Tp = X.Tp;
     {
-        const v3 cm = r + mulv(R, mk(M.com[b][0], M.com[b][1], M.com[b][2]));
-        const float Ib[3][3] = {{M.inertia[b][0], M.inertia[b][3], M.inertia[b][4]}, {M.inertia[b][3], M.inertia[b][1], M.inertia[b][5]},
-                                {M.inertia[b][4], M.inertia[b][5], M.inertia[b][2]}};
+        const v3 cm = r + mulv(R, mk(W.c[b].com[0], W.c[b].com[1], W.c[b].com[2]));
+        const float Ib[3][3] = {{W.c[b].inertia[0], W.c[b].inertia[3], W.c[b].inertia[4]}, {W.c[b].inertia[3], W.c[b].inertia[1], W.c[b].inertia[5]},
+                                {W.c[b].inertia[4], W.c[b].inertia[5], W.c[b].inertia[2]}};
         float RI[3][3], Iw[3][3];
         PARC_UNROLL
         for (int a = 0; a < 3; ++a) {
@@ -247,10 +279,10 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
         sym6 Iown;
         PARC_UNROLL
         for (int i = 0; i < 21; ++i) Iown.s[i] = 0.f;
-        add_inertia(Iown, M.mass[b], cm, Icw);
+        add_inertia(Iown, W.c[b].mass, cm, Icw);
         const s6 Iv = symmul(Iown, B.vel);
         const s6 pb = crf(B.vel, Iv);
-        const v3 fg = mk(0.f, 0.f, M.mass[b] * M.gravity_z);
+        const v3 fg = mk(0.f, 0.f, W.c[b].mass * M.gravity_z);
         const v3 ng = cross(cm, fg);
         PARC_UNROLL
         for (int i = 0; i < 21; ++i) IA.s[i] += Iown.s[i];
@@ -263,10 +295,10 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
     // (exact: those contributions are zero).  The sphere centres lie within brho of the bounding centre, i.e. (brho < one
     // cell) in the 3x3 cells around its cell, and each touches at most the columns one cell further: the 5x5 window.
     v3 fsum = mk(0.f, 0.f, 0.f);
-    const float brho = W.brho[b];
+    const float brho = W.c[b].brho;
     float hmax = 3.0e38f; // highest column any sphere of this body can touch (+inf when the 5x5 window is not applicable)
     {
-        const v3 cb = r + mulv(R, mk(W.bc[b][0], W.bc[b][1], W.bc[b][2]));
+        const v3 cb = r + mulv(R, mk(W.c[b].bc[0], W.c[b].bc[1], W.c[b].bc[2]));
         const int bx = cell_of(cb.x + rootp.x, Tp.min_x, Tp.dx), by = cell_of(cb.y + rootp.y, Tp.min_y, Tp.dy);
         if (brho < X.cell_min && bx >= 2 && bx < DYN_PATCH - 2 && by >= 2 && by < DYN_PATCH - 2) {
             hmax = X.s_pmax[((bx - 2) * WV_PI + by - 2) * 64];
@@ -286,7 +318,7 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
     //          sphere_vs_column / the penetration sign, so the result equals the exhaustive 9-column test of
     //          parc_dynamics.hpp.
     // Lanes with a point outside the staged patch (or a sphere wider than a cell) take the exhaustive path below.
-    const int npt = W.npt[b], pt0 = W.pt0[b];
+    const int npt = W.c[b].npt, pt0 = W.c[b].pt0;
     const float hx = 0.5f * Tp.dx, hy = 0.5f * Tp.dy;
     unsigned hit = 0u;
     bool slow = false;
@@ -296,7 +328,7 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
         struct ColPt { float x, y, z, r; };
         auto load_pt = [&](int pi) __attribute__((always_inline)) {
             const int kp = pt0 + (pi < npt ? pi : 0);
-            ColPt c; c.x = M.col_pos[kp][0]; c.y = M.col_pos[kp][1]; c.z = M.col_pos[kp][2]; c.r = M.col_r[kp];
+            ColPt c; c.x = W.colp[kp][0]; c.y = W.colp[kp][1]; c.z = W.colp[kp][2]; c.r = W.colp[kp][3];
             return c;
         };
         const float fast_r = X.cell_min * 0.5f - 2e-3f;
@@ -352,9 +384,9 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
         if (!__any(mine)) continue; // uniform
         if (mine) {
             const int kp = pt0 + pi;
-            const v3 x = r + mulv(R, mk(M.col_pos[kp][0], M.col_pos[kp][1], M.col_pos[kp][2]));
+            const v3 x = r + mulv(R, mk(W.colp[kp][0], W.colp[kp][1], W.colp[kp][2]));
             const v3 g = x + rootp;
-            const float rad = M.col_r[kp];
+            const float rad = W.colp[kp][3];
             const float zlo = g.z - rad;
             const int pa_ = cell_of(g.x, Tp.min_x, Tp.dx), pb_ = cell_of(g.y, Tp.min_y, Tp.dy); // patch indices = cell indices of the patch frame
             const float top0 = X.s_patch[(pa_ * DYN_PATCH + pb_) * 64];
@@ -393,9 +425,9 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
     if (slow) { // exhaustive test of every point, heights from the patch where it covers them, else from global memory
         for (int pi = 0; pi < npt; ++pi) {
             const int kp = pt0 + pi;
-            const v3 x = r + mulv(R, mk(M.col_pos[kp][0], M.col_pos[kp][1], M.col_pos[kp][2]));
+            const v3 x = r + mulv(R, mk(W.colp[kp][0], W.colp[kp][1], W.colp[kp][2]));
             const v3 g = x + rootp;
-            const float rad = M.col_r[kp];
+            const float rad = W.colp[kp][3];
             const float zlo = g.z - rad;
             if (zlo > hmax) continue;
             const int pa_ = cell_of(g.x, Tp.min_x, Tp.dx), pb_ = cell_of(g.y, Tp.min_y, Tp.dy);
@@ -421,9 +453,9 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
 }
 
 // joint elimination of body b: (IA, pA) -> contribution (Ic, pc) to the parent; K and D^-1 u go to LDS (fac + lane, stride 64)
-__device__ __forceinline__ void wv_joint_inward(const DynModel &M, int b, const WvBody &B, const m3 &R, float dt, const sym6 &IA, const s6 &pA,
+__device__ __forceinline__ void wv_joint_inward(const DynModel &M, const WaveTables &W, int b, const WvBody &B, const m3 &R, float dt, const sym6 &IA, const s6 &pA,
                                                 sym6 &Ic, s6 &pc, float *fac) {
-    const int jt = M.jtype[b], di = M.dof_idx[b];
+    const int jt = W.c[b].jtype, di = W.c[b].dof_idx;
     const v3 r = B.r;
     if (jt == DJ_SPHERICAL) {
         s6 Sc[3], Uc[3];
@@ -435,11 +467,11 @@ __device__ __forceinline__ void wv_joint_inward(const DynModel &M, int b, const 
         const float e3[3] = {err.x, err.y, err.z}, c3[3] = {cur.x, cur.y, cur.z}, q3[3] = {B.qd.x, B.qd.y, B.qd.z};
         PARC_UNROLL
         for (int q = 0; q < 3; ++q) {
-            float t = M.kp[di + q] * e3[q] - (M.kd[di + q] + dt * M.kp[di + q]) * q3[q];
-            t = clampf(t, -M.eff[di + q], M.eff[di + q]);
-            aug[q] = M.arm[di + q] + dt * M.kd[di + q] + dt * dt * M.kp[di + q];
-            if (c3[q] < M.lo[di + q]) { t += M.lim_k * (M.lo[di + q] - c3[q]) - M.lim_d * q3[q]; aug[q] += dt * M.lim_d + dt * dt * M.lim_k; }
-            else if (c3[q] > M.hi[di + q]) { t += M.lim_k * (M.hi[di + q] - c3[q]) - M.lim_d * q3[q]; aug[q] += dt * M.lim_d + dt * dt * M.lim_k; }
+            float t = W.c[b].kp[q] * e3[q] - (W.c[b].kd[q] + dt * W.c[b].kp[q]) * q3[q];
+            t = clampf(t, -W.c[b].eff[q], W.c[b].eff[q]);
+            aug[q] = W.c[b].arm[q] + dt * W.c[b].kd[q] + dt * dt * W.c[b].kp[q];
+            if (c3[q] < W.c[b].lo[q]) { t += M.lim_k * (W.c[b].lo[q] - c3[q]) - M.lim_d * q3[q]; aug[q] += dt * M.lim_d + dt * dt * M.lim_k; }
+            else if (c3[q] > W.c[b].hi[q]) { t += M.lim_k * (W.c[b].hi[q] - c3[q]) - M.lim_d * q3[q]; aug[q] += dt * M.lim_d + dt * dt * M.lim_k; }
             tau[q] = t;
         }
         PARC_UNROLL
@@ -494,13 +526,13 @@ __device__ __forceinline__ void wv_joint_inward(const DynModel &M, int b, const 
             fac[(18 + q) * 64] = du[q];
         }
     } else if (jt == DJ_HINGE) {
-        const v3 a = mulv(R, mk(M.axis[b][0], M.axis[b][1], M.axis[b][2]));
+        const v3 a = mulv(R, mk(W.c[b].axis[0], W.c[b].axis[1], W.c[b].axis[2]));
         const s6 Sc = s6mk(a, cross(r, a));
-        float t = M.kp[di] * (B.thang - B.hang) - (M.kd[di] + dt * M.kp[di]) * B.qd.x;
-        t = clampf(t, -M.eff[di], M.eff[di]);
-        float aug = M.arm[di] + dt * M.kd[di] + dt * dt * M.kp[di];
-        if (B.hang < M.lo[di]) { t += M.lim_k * (M.lo[di] - B.hang) - M.lim_d * B.qd.x; aug += dt * M.lim_d + dt * dt * M.lim_k; }
-        else if (B.hang > M.hi[di]) { t += M.lim_k * (M.hi[di] - B.hang) - M.lim_d * B.qd.x; aug += dt * M.lim_d + dt * dt * M.lim_k; }
+        float t = W.c[b].kp[0] * (B.thang - B.hang) - (W.c[b].kd[0] + dt * W.c[b].kp[0]) * B.qd.x;
+        t = clampf(t, -W.c[b].eff[0], W.c[b].eff[0]);
+        float aug = W.c[b].arm[0] + dt * W.c[b].kd[0] + dt * dt * W.c[b].kp[0];
+        if (B.hang < W.c[b].lo[0]) { t += M.lim_k * (W.c[b].lo[0] - B.hang) - M.lim_d * B.qd.x; aug += dt * M.lim_d + dt * dt * M.lim_k; }
+        else if (B.hang > W.c[b].hi[0]) { t += M.lim_k * (W.c[b].hi[0] - B.hang) - M.lim_d * B.qd.x; aug += dt * M.lim_d + dt * dt * M.lim_k; }
         const s6 Uc = symmul(IA, Sc);
         float sp = 0.f, d = aug;
         PARC_UNROLL
@@ -527,8 +559,8 @@ __device__ __forceinline__ void wv_joint_inward(const DynModel &M, int b, const 
 }
 
 // acceleration of body b from its parent's (ap); leaves its own in ap
-__device__ __forceinline__ void wv_joint_outward(const DynModel &M, int b, WvBody &B, s6 &ap, const float *fac) {
-    const int jt = M.jtype[b];
+__device__ __forceinline__ void wv_joint_outward(const DynModel &M, const WaveTables &W, int b, WvBody &B, s6 &ap, const float *fac) {
+    const int jt = W.c[b].jtype;
     s6 ai = ap + B.cJ;
     if (jt == DJ_SPHERICAL) {
         float q3[3];
@@ -548,14 +580,14 @@ __device__ __forceinline__ void wv_joint_outward(const DynModel &M, int b, WvBod
         for (int a = 0; a < 6; ++a) ka += fac[a * 64] * ai.a[a];
         const float qa = fac[6 * 64] - ka;
         B.qdd = mk(qa, 0.f, 0.f);
-        const v3 wj = qa * mulv(qmat(B.bq), mk(M.axis[b][0], M.axis[b][1], M.axis[b][2]));
+        const v3 wj = qa * mulv(qmat(B.bq), mk(W.c[b].axis[0], W.c[b].axis[1], W.c[b].axis[2]));
         ai = ai + s6mk(wj, cross(B.r, wj));
     }
     ap = ai;
 }
 
-__device__ __forceinline__ void wv_integrate_joint(const DynModel &M, int b, WvBody &B, float dt) {
-    const int jt = M.jtype[b];
+__device__ __forceinline__ void wv_integrate_joint(const DynModel &M, const WaveTables &W, int b, WvBody &B, float dt) {
+    const int jt = W.c[b].jtype;
     const float mw = M.max_ang_vel;
     if (jt == DJ_SPHERICAL) {
         B.qd = mk(clampf(B.qd.x + dt * B.qdd.x, -mw, mw), clampf(B.qd.y + dt * B.qdd.y, -mw, mw), clampf(B.qd.z + dt * B.qdd.z, -mw, mw));
@@ -566,8 +598,8 @@ __device__ __forceinline__ void wv_integrate_joint(const DynModel &M, int b, WvB
     }
 }
 
-__device__ __forceinline__ void wv_store_joint(const DynModel &M, int b, const WvBody &B, float *dp, float *dv, float *cf) {
-    const int jt = M.jtype[b], di = M.dof_idx[b];
+__device__ __forceinline__ void wv_store_joint(const DynModel &M, const WaveTables &W, int b, const WvBody &B, float *dp, float *dv, float *cf) {
+    const int jt = W.c[b].jtype, di = W.c[b].dof_idx;
     // plain copies first: selecting between struct fields inside the branches would keep the body in scratch
     const q4 jq = B.jq; const float hang = B.hang; const v3 qd = B.qd, fc = B.fcon;
     if (jt == DJ_SPHERICAL) {
@@ -607,8 +639,8 @@ __global__ __launch_bounds__(256, 1) WV_EXTRA_ATTR void k_dynamics_wave(const Dy
     WvBody limb[WV_MAXLEN], trunk[WV_MAXLEN];
     PARC_UNROLL
     for (int k = 0; k < WV_MAXLEN; ++k) {
-        if (k < llen) wv_load_joint(M, W.body[lc][k], limb[k], dp, dv, ac);
-        if (k < tlen) wv_load_joint(M, W.body[0][k], trunk[k], dp, dv, ac);
+        if (k < llen) wv_load_joint(M, W, W.body[lc][k], limb[k], dp, dv, ac);
+        if (k < tlen) wv_load_joint(M, W, W.body[0][k], trunk[k], dp, dv, ac);
     }
     const v3 rp_buf = mk(buf.char_root_pos[3 * ec], buf.char_root_pos[3 * ec + 1], buf.char_root_pos[3 * ec + 2]);
     q4 rq; rq.x = buf.char_root_rot[4 * ec]; rq.y = buf.char_root_rot[4 * ec + 1]; rq.z = buf.char_root_rot[4 * ec + 2]; rq.w = buf.char_root_rot[4 * ec + 3];
@@ -699,7 +731,7 @@ __global__ __launch_bounds__(256, 1) WV_EXTRA_ATTR void k_dynamics_wave(const Dy
             PARC_UNROLL
             for (int k = 0; k < WV_MAXLEN; ++k) {
                 if (k < tlen) {
-                    wv_fk_body(M, W.body[0][k], trunk[k], pq, pr, pv);
+                    wv_fk_body(M, W, W.body[0][k], trunk[k], pq, pr, pv);
                     const int slot = W.att_slot[k];
                     if (slot >= 0) {
                         float *s = s_attkin + slot * 13 * 64;
@@ -728,7 +760,7 @@ __global__ __launch_bounds__(256, 1) WV_EXTRA_ATTR void k_dynamics_wave(const Dy
             sym6 IA = Icl; s6 pA = pcl;
             WSTAMP(15);
             wv_body_inertia(M, W, T, X, b, limb[k], R, rootp, IA, pA WSTAMP_ARGS);
-            wv_joint_inward(M, b, limb[k], R, dt, IA, pA, Icl, pcl, s_fac + W.fac_off[lc][k] * 64);
+            wv_joint_inward(M, W, b, limb[k], R, dt, IA, pA, Icl, pcl, s_fac + W.fac_off[lc][k] * 64);
             WPIN(Icl, pcl);
             WSTAMP(14);
         };
@@ -747,7 +779,7 @@ __global__ __launch_bounds__(256, 1) WV_EXTRA_ATTR void k_dynamics_wave(const Dy
             PARC_UNROLL
             for (int a = 0; a < 6; ++a) pv.a[a] = s[(7 + a) * 64];
             PARC_UNROLL
-            for (int k = 0; k < WV_MAXLEN; ++k) if (k < llen) wv_fk_body(M, W.body[lc][k], limb[k], pq, pr, pv);
+            for (int k = 0; k < WV_MAXLEN; ++k) if (k < llen) wv_fk_body(M, W, W.body[lc][k], limb[k], pq, pr, pv);
             WSTAMP(11);
             PARC_UNROLL
             for (int k = WV_MAXLEN - 1; k >= 0; --k)
@@ -824,7 +856,7 @@ __global__ __launch_bounds__(256, 1) WV_EXTRA_ATTR void k_dynamics_wave(const Dy
                 PARC_UNROLL
                 for (int a = 0; a < 6; ++a) acc_root.a[a] = xs[a];
             } else {
-                wv_joint_inward(M, b, trunk[k], R, dt, IA, pA, Ict, pct, s_fac + W.fac_off[0][k] * 64);
+                wv_joint_inward(M, W, b, trunk[k], R, dt, IA, pA, Ict, pct, s_fac + W.fac_off[0][k] * 64);
             }
         };
         if (w == 0) { // part B, trunk: every body but the root
@@ -875,7 +907,7 @@ __global__ __launch_bounds__(256, 1) WV_EXTRA_ATTR void k_dynamics_wave(const Dy
             for (int k = 0; k < WV_MAXLEN; ++k) {
                 if (k < tlen) {
                     const int b = W.body[0][k];
-                    if (b != 0) wv_joint_outward(M, b, trunk[k], ap, s_fac + W.fac_off[0][k] * 64);
+                    if (b != 0) wv_joint_outward(M, W, b, trunk[k], ap, s_fac + W.fac_off[0][k] * 64);
                     const int slot = W.att_slot[k];
                     if (slot >= 0) {
                         PARC_UNROLL
@@ -896,7 +928,7 @@ __global__ __launch_bounds__(256, 1) WV_EXTRA_ATTR void k_dynamics_wave(const Dy
                 rq = qnormalize(qmul(qexp(dt * rw), rq));
             }
             PARC_UNROLL
-            for (int k = 0; k < WV_MAXLEN; ++k) if (k < tlen) wv_integrate_joint(M, W.body[0][k], trunk[k], dt);
+            for (int k = 0; k < WV_MAXLEN; ++k) if (k < tlen) wv_integrate_joint(M, W, W.body[0][k], trunk[k], dt);
         }
         WSTAMP(7);
         __syncthreads();
@@ -910,8 +942,8 @@ __global__ __launch_bounds__(256, 1) WV_EXTRA_ATTR void k_dynamics_wave(const Dy
             for (int k = 0; k < WV_MAXLEN; ++k) {
                 if (k < llen) {
                     const int b = W.body[lc][k];
-                    wv_joint_outward(M, b, limb[k], ap, s_fac + W.fac_off[lc][k] * 64);
-                    wv_integrate_joint(M, b, limb[k], dt);
+                    wv_joint_outward(M, W, b, limb[k], ap, s_fac + W.fac_off[lc][k] * 64);
+                    wv_integrate_joint(M, W, b, limb[k], dt);
                 }
             }
         }
@@ -934,8 +966,8 @@ __global__ __launch_bounds__(256, 1) WV_EXTRA_ATTR void k_dynamics_wave(const Dy
     }
     PARC_UNROLL
     for (int k = 0; k < WV_MAXLEN; ++k) {
-        if (k < llen) wv_store_joint(M, W.body[lc][k], limb[k], odp, odv, ocf);
-        if (k < tlen) wv_store_joint(M, W.body[0][k], trunk[k], odp, odv, ocf);
+        if (k < llen) wv_store_joint(M, W, W.body[lc][k], limb[k], odp, odv, ocf);
+        if (k < tlen) wv_store_joint(M, W, W.body[0][k], trunk[k], odp, odv, ocf);
     }
 #ifdef PARC_STAMPS
     WSTAMP(10);
