@@ -169,26 +169,30 @@ __global__ __launch_bounds__(64) void k_dynamics(const parcdyn::DynModel *__rest
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_env_prep: one THREAD per env for the work that is scalar per env and transcendental-heavy — heading,
-// inverse heading quaternion, cos/sin of the heading for the ray fan, and dof -> joint quaternion of the
-// character (kin_char_model.py:586; torch_util.py:502-530).  In the wave-per-env kernel these ran with 1-14
-// active lanes; here 64 envs share every instruction.  Output: a 256-byte record per env (L2/Infinity-Cache
-// resident between the two launches).
+// k_env_prep: the work that is scalar per env and transcendental-heavy — heading, inverse heading quaternion,
+// cos/sin of the heading for the ray fan, and dof -> joint quaternion of the character (kin_char_model.py:586;
+// torch_util.py:502-530).  In the wave-per-env kernel these would run with 15 of 64 lanes (measured: +35 us at 65 536
+// envs when folded in, against the 22 us of this kernel); here all lanes are busy.  Output: a 256-byte record per env
+// (L2 / Infinity-Cache resident between the two launches).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_env_prep(const StepParams P, const int64_t *__restrict__ env_ids,
                                                  const int *__restrict__ env_ids32, const int *__restrict__ count_dev, int count) {
+    // 16 lanes per env (4 envs per wave): lane 0 forms the heading terms, lane j the quaternion of joint j.  One
+    // transcendental chain per lane instead of fifteen per thread: the same instruction count at 65 536 envs, a 10x shorter
+    // critical path at the few thousand envs of a multi-GPU shard.
     if (count_dev) count = *count_dev;
-    const int it = blockIdx.x * blockDim.x + threadIdx.x;
-    if (it >= count) return;
+    const int it = blockIdx.x * 4 + (threadIdx.x >> 4), j = threadIdx.x & 15;
+    if (it >= count || j >= P.B) return;
     const int e = env_ids ? (int)env_ids[it] : (env_ids32 ? env_ids32[it] : it);
     const DevTables *__restrict__ T = P.tables;
-    const float4 rr = *(const float4 *)(P.buf.char_root_rot + 4 * (size_t)e);
-    const float heading = calc_heading(rr);
-    const Q4 hinv = heading_quat_inv(heading);
     float4 *out = P.prep + (size_t)e * 16;
-    out[0] = make_float4(cosf(heading), sinf(heading), hinv.z, hinv.w);
-    const float *dof = P.buf.char_dof_pos + (size_t)e * P.D;
-    for (int j = 1; j < P.B; ++j) {
+    if (j == 0) {
+        const float4 rr = *(const float4 *)(P.buf.char_root_rot + 4 * (size_t)e);
+        const float heading = calc_heading(rr);
+        const Q4 hinv = heading_quat_inv(heading);
+        out[0] = make_float4(cosf(heading), sinf(heading), hinv.z, hinv.w);
+    } else {
+        const float *dof = P.buf.char_dof_pos + (size_t)e * P.D;
         const int ty = T->h.jtype[j], di = T->h.dof_idx[j];
         Q4 q = mk4(0.f, 0.f, 0.f, 1.f);
         if (ty == PARC_JOINT_HINGE) q = axis_angle_to_quat(mk3(T->h.axis[j][0], T->h.axis[j][1], T->h.axis[j][2]), dof[di]);
@@ -1582,7 +1586,7 @@ static int launch_post(ParcEnv *e, int mode, const int64_t *ids, int count, hipS
                        const int *count_dev = nullptr, bool prep_done = false) {
     if (count <= 0) return PARC_OK;
     const int grid = count;
-    if (!prep_done) hipLaunchKernelGGL(k_env_prep, dim3((count + 63) / 64), dim3(64), 0, st, e->sp, ids, ids32, count_dev, count);
+    if (!prep_done) hipLaunchKernelGGL(k_env_prep, dim3((count + 3) / 4), dim3(64), 0, st, e->sp, ids, ids32, count_dev, count);
     if (mode == MODE_STEP) hipLaunchKernelGGL(k_env_post<MODE_STEP>, dim3(grid), dim3(64), e->lds_bytes, st, e->sp, ids, ids32, count_dev, count);
     else hipLaunchKernelGGL(k_env_post<MODE_OBS>, dim3(grid), dim3(64), e->lds_bytes, st, e->sp, ids, ids32, count_dev, count);
     HIPCHK(hipGetLastError());
