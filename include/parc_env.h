@@ -210,6 +210,9 @@ int parc_env_get_fail_rates(ParcEnv *env, float *out_host, int32_t M);
 int parc_env_set_fail_rates(ParcEnv *env, const float *in_host, int32_t M);
 /* per-motion tables derived at load (motion_lib.py:361-384); any pointer may be NULL */
 int parc_env_get_motion_info(ParcEnv *env, float *lengths_host, float *weights_host, int32_t M);
+/* `never_done` (ig_parkour_env.py:59,980): done flags read NULL after update_done, so the agent resets nothing and
+ * parc_env_reset_done resets nobody; the fail-rate curriculum still sees the episode ends, as in the reference. */
+int parc_env_set_never_done(ParcEnv *env, int32_t never_done);
 int parc_env_set_rand_reset(ParcEnv *env, int32_t rand_reset, int32_t demo_mode, float root_pos_offset_scale);
 int parc_env_set_start_time_fraction(ParcEnv *env, const float *frac_dev /* [N] or NULL */);
 

@@ -75,7 +75,7 @@ struct StepParams {
     float dt_f, episode_length, min_obs_h, max_obs_h;
     float pose_w, vel_w, root_pos_w, root_vel_w, key_pos_w;
     float root_pos_term_sq, root_rot_term;
-    int early_term, pose_term, track_root, track_root_h, tracking, body_pos_from_fk;
+    int early_term, pose_term, track_root, track_root_h, tracking, body_pos_from_fk, never_done;
     // terrain
     const float *hf; int X, Y; float min_x, min_y, dx, dy; int tile_r;
     float rdx, rdy;      // correctly rounded 1/dx, 1/dy (host): the ray loop divides by multiply + one exact correction
@@ -639,6 +639,7 @@ __global__ __launch_bounds__(64, 4) void k_env_post(const StepParams P, const in
         unsigned char code = 0;
         if (done != PARC_DONE_NULL || motion_end) code = (done == PARC_DONE_FAIL) ? 1 : 2;
         if (motion_end) done = PARC_DONE_FAIL;
+        if (P.never_done) done = PARC_DONE_NULL; // ig_parkour_env.py:980: after update_done (the curriculum still sees the episode end)
         if (lane == 0) {
             P.buf.reward[e] = rew;
             P.buf.done[e] = done;
@@ -732,7 +733,7 @@ __device__ __forceinline__ int nonzero_bytes(unsigned v) {
 // Block b owns envs [1024 b, 1024 b + 1024).  Its base offset = number of finished envs before it, which it
 // counts itself from the (1 byte per env) code array: no atomics in the step kernel, no second launch.
 __global__ __launch_bounds__(1024) void k_done_scatter(const unsigned char *__restrict__ ema_code, const int *__restrict__ motion_ids,
-                                                       int N, int *done_list, int *done_key, int *reset_count) {
+                                                       int N, int *done_list, int *done_key, int *reset_count, int never_done) {
     __shared__ int s_base, s_wave[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.x;
     if (tid == 0) s_base = 0;
@@ -760,7 +761,10 @@ __global__ __launch_bounds__(1024) void k_done_scatter(const unsigned char *__re
         done_list[pos] = e;
         done_key[pos] = (motion_ids[e] << 1) | (code == 1 ? 1 : 0);
     }
-    if (b == (int)gridDim.x - 1 && tid == 0) *reset_count = s_base + total;
+    if (b == (int)gridDim.x - 1 && tid == 0) {
+        reset_count[0] = s_base + total;                   // entries of the list: the fail-rate EMA walks all of them
+        reset_count[1] = never_done ? 0 : s_base + total;  // envs parc_env_reset_done resets (never_done: flags are NULL, nobody)
+    }
 }
 
 // One 256-thread block per motion.  The block sweeps the env-ordered list and compacts (stable, by rank) the
@@ -1358,7 +1362,7 @@ extern "C" int parc_env_create(const ParcEnvConfig *cfg, ParcEnv **out) {
         (r = up((void **)&e->d_done_list, nullptr, sizeof(int) * N)) != hipSuccess ||
         (r = up((void **)&e->d_done_key, nullptr, sizeof(int) * N)) != hipSuccess ||
         (r = up((void **)&e->d_chunk_count, nullptr, sizeof(int) * 1024)) != hipSuccess ||
-        (r = up((void **)&e->d_reset_count, nullptr, sizeof(int))) != hipSuccess ||
+        (r = up((void **)&e->d_reset_count, nullptr, 2 * sizeof(int))) != hipSuccess ||
         (r = up((void **)&e->d_reset_calls, nullptr, sizeof(unsigned long long))) != hipSuccess ||
         (r = up((void **)&e->d_tmp_mid, nullptr, sizeof(int) * N)) != hipSuccess ||
         (r = up((void **)&e->d_tmp_tid, nullptr, sizeof(int) * N)) != hipSuccess ||
@@ -1575,7 +1579,7 @@ static int launch_dynamics(ParcEnv *e, const float *action_dev, hipStream_t st) 
 
 static int launch_curriculum(ParcEnv *e, hipStream_t st) {
     hipLaunchKernelGGL(k_done_scatter, dim3(e->nchunks), dim3(1024), 0, st, e->d_ema, e->sp.buf.motion_ids, e->N, e->d_done_list,
-                       e->d_done_key, e->d_reset_count);
+                       e->d_done_key, e->d_reset_count, e->sp.never_done);
     hipLaunchKernelGGL(k_fail_rate_ema, dim3(e->M), dim3(1024), 0, st, e->d_done_key, e->d_reset_count, e->d_fail, e->M,
                        e->cfg.fail_rate_ema_weight);
     HIPCHK(hipGetLastError());
@@ -1827,13 +1831,16 @@ extern "C" int parc_env_reset_done(ParcEnv *e, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     const int n = e->N;
     hipLaunchKernelGGL(k_build_cdf, dim3(1), dim3(1024), 0, st, e->d_fail, e->d_weights, e->cfg.min_motion_weight, e->M, e->d_cdf, e->d_reset_calls);
-    hipLaunchKernelGGL(k_reset_sample, dim3((n + 127) / 128), dim3(128), 0, st, (const int64_t *)nullptr, e->d_done_list, e->d_reset_count, n, e->M,
+    hipLaunchKernelGGL(k_reset_sample, dim3((n + 127) / 128), dim3(128), 0, st, (const int64_t *)nullptr, e->d_done_list, e->d_reset_count + 1, n, e->M,
                        e->T, e->d_cdf, e->d_meta, (unsigned long long)e->cfg.seed, (const unsigned long long *)e->d_reset_calls, e->cfg.rand_reset, e->cfg.demo_mode,
                        e->cfg.rand_root_pos_offset_scale, e->d_start_frac, e->d_tmp_mid, e->d_tmp_tid, e->d_tmp_t0, e->d_tmp_noise);
     hipLaunchKernelGGL(k_reset_with, dim3((n + 3) / 4), dim3(64), 0, st, make_reset_params(e), (const int64_t *)nullptr, e->d_done_list,
-                       e->d_reset_count, n, e->d_tmp_mid, e->d_tmp_tid, e->d_tmp_t0, e->d_tmp_noise);
+                       e->d_reset_count + 1, n, e->d_tmp_mid, e->d_tmp_tid, e->d_tmp_t0, e->d_tmp_noise);
     HIPCHK(hipGetLastError());
-    return launch_post(e, MODE_OBS, nullptr, n, st, e->d_done_list, e->d_reset_count, /*prep_done=*/true);
+    rc = launch_post(e, MODE_OBS, nullptr, n, st, e->d_done_list, e->d_reset_count + 1, /*prep_done=*/true);
+    if (rc) return rc;
+    HIPCHK(hipMemsetAsync(e->d_reset_count + 1, 0, sizeof(int), st)); // the list is consumed: a second call before the next step resets nobody
+    return PARC_OK;
 }
 
 // ---- whole control step as one hipGraph launch ----------------------------------------------------------------------
@@ -1900,6 +1907,12 @@ extern "C" int parc_env_get_motion_info(ParcEnv *e, float *lengths, float *weigh
         if (weights) weights[m] = e->h_weights[m];
     }
     return PARC_OK;
+}
+
+extern "C" int parc_env_set_never_done(ParcEnv *e, int32_t never_done) {
+    if (!e) return fail(PARC_ERR_INVALID, "null env");
+    e->sp.never_done = never_done != 0;
+    return sync_params(e);
 }
 
 extern "C" int parc_env_set_rand_reset(ParcEnv *e, int32_t rand_reset, int32_t demo_mode, float scale) {

@@ -145,6 +145,8 @@ class HipParkourEnv(base_env.BaseEnv):
             print("LOADING SAVED FAIL RATES")
             fr = torch.load(env_config["dm"]["fail_rates_path"], weights_only=True).to(dtype=torch.float32).cpu().numpy()
             self.set_fail_rates(fr)
+        if self._never_done:  # ig_parkour_env.py:980: the kernel writes NULL flags and an empty reset list
+            L.check(self._lib.parc_env_set_never_done(self._handle, 1))
         self._dm_view = _DMView(self)
         self._info = dict()
         self.set_write_agent_states_flag(env_config.get("write_agent_states", False))
@@ -256,8 +258,6 @@ class HipParkourEnv(base_env.BaseEnv):
             assert action.shape == (self._num_envs, self._char_dof_pos.shape[1]) and action.dtype == torch.float32
             a = action.contiguous().data_ptr()
         L.check(self._lib.parc_env_step(self._handle, a, self._stream()))
-        if self._never_done:
-            self._done_buf[:] = base_env.DoneFlags.NULL.value
         self.write_agent_states()  # ig_parkour_env.py:686-696: after update_done, before the agent resets anything
         self._update_info()
         return self._obs_buf, self._reward_buf, self._done_buf, self._info
