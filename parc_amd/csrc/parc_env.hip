@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -38,17 +39,18 @@ using namespace parc;
 #define REC_Q_CONTACT 16     // float4 #16..19 = contacts
 #define REC_Q_VEL 20         // float4 #20 = root_vel, #21 = root_ang_vel, #22.. = dof_vel
 
-struct HierTables { // joint hierarchy: the part of the per-body tables every wave stages into LDS
-    int parent[16];
-    int jtype[16];
-    int dof_idx[16];
-    float axis[16][4];
+struct HierTables { // joint hierarchy.  The members up to `parent` are what every wave of k_env_post stages into LDS
     float lt[16][4];
     float lr[16][4];
     int fk_paths[PARC_MAX_FK_PATHS][PARC_MAX_FK_DEPTH];
     int key_ids[8];
     int key_slot[16]; // body -> index into key_ids, or -1
+    int parent[16];   // ---- not staged (read from global memory where needed) ----
+    int jtype[16];
+    int dof_idx[16];
+    float axis[16][4];
 };
+#define HIER_STAGED_WORDS ((int)(offsetof(HierTables, parent) / 4))
 
 #define TILE_MAX_CELLS 320 // the terrain tile aliases the FK scratch (80 float4)
 
@@ -227,10 +229,10 @@ __global__ __launch_bounds__(64, 4) void k_env_post(const StepParams P, const in
     // P arrives by value in the kernarg segment: its pointers are then known to be global (global_load / global_store
     // instead of flat_*, which would also tie up the LDS wait counter), its scalars are scalar loads where they are used
     extern __shared__ __align__(16) float s_obs[]; // staged observation prefix [0, off_tarc)
-    __shared__ HierTables s_tab;
+    __shared__ int s_tab_raw[HIER_STAGED_WORDS];
+    const HierTables &s_tab = *reinterpret_cast<const HierTables *>(s_tab_raw); // only the staged members are touched through it
     __shared__ float4 s_q[8][16];   // row r: quats 0..14 (0 = root), slot 15 = root position
     __shared__ float4 s_fk[80];     // FK positions: rows 0,1 all bodies [r*16+b]; target rows key slots [32+(r-2)*8+k]
-    __shared__ float4 s_br[2][16];  // body rotations of char/ref (tracking error only)
     __shared__ float4 s_cbp[16];    // simulator rigid-body positions of the character
     __shared__ float4 s_rpo[8];     // per target row: heading-frame root offset
     __shared__ float s_cdofv[PARC_MAX_DOFS];
@@ -241,6 +243,8 @@ __global__ __launch_bounds__(64, 4) void k_env_post(const StepParams P, const in
     __shared__ unsigned long long s_stamp[16];
 #endif
     float *s_tile = (float *)s_fk;  // the terrain tile is dead before FK writes s_fk
+    float4 (*s_br)[16] = reinterpret_cast<float4 (*)[16]>(s_obs + ((P.off_tarc + 3) & ~3)); // body rotations of char/ref: only allocated
+                                                                                            // (behind the staged prefix) when the tracking error is reported
 
     const int lane = threadIdx.x;
     if (count_dev) count = *count_dev; // device-side list (reset_done): no host round trip
@@ -257,7 +261,7 @@ __global__ __launch_bounds__(64, 4) void k_env_post(const StepParams P, const in
 
     // ================= prefetch: every global load of this env is issued before any is consumed =================
     // (a) loads that only need the env id go first, so they overlap the scalar bookkeeping chain below
-    constexpr int HW = (int)(sizeof(HierTables) / 4);
+    constexpr int HW = HIER_STAGED_WORDS;
     constexpr int HN = (HW + 63) / 64;
     int tabreg[HN];
 #pragma unroll
@@ -357,7 +361,7 @@ __global__ __launch_bounds__(64, 4) void k_env_post(const StepParams P, const in
     const float ch = __shfl(prepq.x, 0, 64), sh = __shfl(prepq.y, 0, 64);
     const Q4 hinv = mk4(0.f, 0.f, __shfl(prepq.z, 0, 64), __shfl(prepq.w, 0, 64)); // axis_angle_to_quat(z, -heading): x = y = 0 exactly
 #pragma unroll
-    for (int i = 0; i < HN; ++i) { const int w = lane + 64 * i; if (w < HW) ((int *)&s_tab)[w] = tabreg[i]; }
+    for (int i = 0; i < HN; ++i) { const int w = lane + 64 * i; if (w < HW) s_tab_raw[w] = tabreg[i]; }
     if (lane < D) {
         s_cdofv[lane] = dofv;
         s_obs[P.off_dofvel + lane] = dofv;
@@ -662,11 +666,11 @@ __global__ __launch_bounds__(64, 4) void k_env_post(const StepParams P, const in
             o[0] = v.x; o[1] = v.y; o[2] = v.z;
         }
         if (P.buf.ref_dof_pos && lane >= 1 && lane < B) { // kin_char_model.py:601
-            const int ty = s_tab.jtype[lane];
+            const int ty = T->h.jtype[lane];
             float out3[3] = {0.f, 0.f, 0.f};
-            joint_rot_to_dof(ty, s_tab.axis[lane], s_q[1][lane], out3);
+            joint_rot_to_dof(ty, T->h.axis[lane], s_q[1][lane], out3);
             const int nd = ty == PARC_JOINT_HINGE ? 1 : (ty == PARC_JOINT_SPHERICAL ? 3 : 0);
-            for (int k = 0; k < nd; ++k) P.buf.ref_dof_pos[(size_t)e * D + s_tab.dof_idx[lane] + k] = out3[k];
+            for (int k = 0; k < nd; ++k) P.buf.ref_dof_pos[(size_t)e * D + T->h.dof_idx[lane] + k] = out3[k];
         }
         if (P.tracking && P.buf.tracking_error) { // mgdm_dm_util.py:521-553
             float e_rot = 0.f, e_pos = 0.f, e_dv = 0.f;
@@ -1530,7 +1534,7 @@ extern "C" int parc_env_load_terrain(ParcEnv *e, const float *hf, int32_t X, int
         sp.tile_mul = mul;
     }
     const int stage_pad = (sp.off_tarc + 3) & ~3;
-    e->lds_bytes = sizeof(float) * (size_t)stage_pad;
+    e->lds_bytes = sizeof(float) * (size_t)stage_pad + (e->cfg.report_tracking_error ? 2 * 16 * sizeof(float4) : 0);
     e->have_terrain = true;
     e->graph_dirty = true;
     return sync_params(e);
