@@ -340,7 +340,8 @@ def main():
             if not os.environ.get("PARC_BENCH_SHARE_GPU"):
                 sys.exit(f"bench.py: --gpus {a.gpus} but {ngpu} GPU(s) visible (set PARC_BENCH_SHARE_GPU=1 to rehearse all ranks on one GPU)")
         rc, out0 = launch_ranks(a.gpus, sys.argv[1:], extra_env=extra)
-        sys.stdout.write(out0)
+        js = [ln for ln in out0.splitlines() if ln.startswith("{")]  # (gloo's C++ side prints a connection notice to stdout)
+        sys.stdout.write((js[-1] + "\n") if js else out0)
         sys.exit(rc)
     worker(a)
 

@@ -839,6 +839,43 @@ __global__ __launch_bounds__(1024) void k_fail_rate_ema(const int *__restrict__ 
     if (tid == 0 && any) fail_rates[m] = s_f;
 }
 
+// Large libraries (thousands of motions, a handful of finished envs each): one block per motion sweeping the whole list is
+// O(M k).  Instead the FIRST list entry of every motion that occurs becomes its leader (atomicMin over a per-motion slot
+// that is kept at INT_MAX between steps), and the leader walks the list once, applying its motion's entries in list
+// (= env) order: the same chain, the same roundings, O(k) per motion that actually finished an env.
+__global__ void k_ema_first(const int *__restrict__ done_key, const int *__restrict__ reset_count, int *first) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= *reset_count) return;
+    atomicMin(&first[done_key[i] >> 1], i);
+}
+
+__global__ __launch_bounds__(256) void k_ema_leader(const int *__restrict__ done_key, const int *__restrict__ reset_count, int *first,
+                                                    float *fail_rates, float w) {
+    // one WAVE per list entry; only the waves of leaders do anything.  The 64 lanes sweep the rest of the list 64 entries at
+    // a time (one coalesced load, two ballots); lane 0 applies the matching entries of a tile in list order.
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const int k = *reset_count;
+    if (i >= k) return;
+    const int m = done_key[i] >> 1;
+    if (first[m] != i) return;
+    const float keep = (float)(1.0 - (double)w);
+    float f = fail_rates[m];
+    for (int j0 = i & ~63; j0 < k; j0 += 64) {
+        const int j = j0 + lane;
+        const int key = j < k ? done_key[j] : -2;
+        const bool match = j >= i && (key >> 1) == m;
+        unsigned long long mm = __ballot(match);
+        const unsigned long long ff = __ballot(match && (key & 1));
+        while (mm) { // uniform: every lane runs the same chain, lane 0 stores
+            const int t = __builtin_ctzll(mm);
+            mm &= mm - 1ull;
+            f = f * keep;
+            f = f + (((ff >> t) & 1ull) ? w : 0.0f);
+        }
+    }
+    if (lane == 0) { fail_rates[m] = f; first[m] = 0x7fffffff; }
+}
+
 // ------------------------------------------------------------------------------------------------
 // motion library preparation (motion_lib.py:305-327, kin_char_model.py:651-693): one thread per frame
 // ------------------------------------------------------------------------------------------------
@@ -1152,25 +1189,48 @@ __device__ __forceinline__ void philox4(unsigned long long seed, unsigned long l
 }
 
 // weights = clamp(fail_rate, min_w) * motion_weight (dm_env.py:487-490) -> inclusive CDF (one block)
+__device__ __forceinline__ double shfl_up_f64(double v, int d) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __shfl_up((int)(b & 0xffffffffll), d, 64), hi = __shfl_up((int)(b >> 32), d, 64);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 __global__ __launch_bounds__(1024) void k_build_cdf(const float *fail_rates, const float *motion_weights, float min_w, int M, float *cdf,
                                                     unsigned long long *reset_calls) {
     if (threadIdx.x == 0) *reset_calls += 1ull; // index of this reset call for the Philox stream (device-side, so that a
                                                 // captured graph replays with a fresh index every time)
-    __shared__ double s_part[1024];
-    const int per = (M + 1023) / 1024;
-    const int b = threadIdx.x * per, eend = min(M, b + per);
-    double s = 0.0;
-    for (int m = b; m < eend; ++m) s += (double)(fmaxf(fail_rates[m], min_w) * motion_weights[m]);
-    s_part[threadIdx.x] = s;
+    // rows of 1024 consecutive motions (coalesced); inside a row: wave scans through shuffles, the 16 wave totals through LDS;
+    // the running total carries from row to row.  Sums are formed in double, the stored value is its fp32 rounding.
+    __shared__ double s_wave[16];
+    __shared__ double s_carry;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0.0;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) { // inclusive block scan of the per-thread sums
-        const double v = threadIdx.x >= off ? s_part[threadIdx.x - off] : 0.0;
-        __syncthreads();
-        s_part[threadIdx.x] += v;
-        __syncthreads();
+    for (int base0 = 0; base0 < M; base0 += 16 * 1024) { // 16 rows per pass: their loads are all in flight before the first scan
+        float pv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = base0 + r * 1024 + threadIdx.x;
+            pv[r] = m < M ? fmaxf(fail_rates[m], min_w) * motion_weights[m] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int base = base0 + r * 1024;
+            if (base >= M) break; // uniform
+            const int m = base + threadIdx.x;
+            double v = (double)pv[r];
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const double u = shfl_up_f64(v, d); if (lane >= d) v += u; }
+            if (lane == 63) s_wave[wv] = v;
+            __syncthreads();
+            double off = s_carry;
+            for (int q = 0; q < wv; ++q) off += s_wave[q];
+            if (m < M) cdf[m] = (float)(off + v);
+            __syncthreads();
+            if (threadIdx.x == 1023) s_carry = off + v;
+            __syncthreads();
+        }
     }
-    double acc = threadIdx.x > 0 ? s_part[threadIdx.x - 1] : 0.0; // exclusive prefix of this thread's range
-    for (int m = b; m < eend; ++m) { acc += (double)(fmaxf(fail_rates[m], min_w) * motion_weights[m]); cdf[m] = (float)acc; }
 }
 
 __global__ void k_reset_sample(const int64_t *env_ids, const int *env_ids32, const int *count_dev, int k, int M, int T, const float *cdf, const MotionMeta *meta,
@@ -1242,6 +1302,7 @@ struct ParcEnv {
     const float *action_bound = nullptr;           // parc_env_bind_action
     hipGraphExec_t graph_exec = nullptr;           // parc_env_step_reset_graph
     bool graph_dirty = true;
+    bool force_ema_leader = false;                 // test switch PARC_EMA_LEADER=1: the large-library EMA path on a small library
     int grid_waves = 0;
     size_t lds_bytes = 0;
     float last_dyn_ms = 0.f;
@@ -1407,6 +1468,7 @@ extern "C" int parc_env_create(const ParcEnvConfig *cfg, ParcEnv **out) {
             return fail(PARC_ERR_HIP, std::string("dynamics kernel setup failed: ") + hipGetErrorString(r));
         }
     }
+    e->force_ema_leader = getenv("PARC_EMA_LEADER") != nullptr;
     for (auto &ev : e->ev) (void)hipEventCreate(&ev);
     sp.tables = e->d_tab; sp.ray_points = e->d_ray; sp.env_offsets = e->d_env_off;
     sp.ema_code = e->d_ema; sp.prep = e->d_prep;
@@ -1471,7 +1533,7 @@ extern "C" int parc_env_load_motions(ParcEnv *e, const ParcMotionClips *c) {
     HIPCHK(hipMalloc((void **)&e->d_fail, sizeof(float) * M));
     HIPCHK(hipMalloc((void **)&e->d_cdf, sizeof(float) * M));
     HIPCHK(hipMalloc((void **)&e->d_motion_done, sizeof(int) * M));
-    HIPCHK(hipMemset(e->d_motion_done, 0, sizeof(int) * M));
+    HIPCHK(hipMemset(e->d_motion_done, 0x7f, sizeof(int) * M)); // 0x7f7f7f7f: larger than any list index (k_ema_first takes the minimum)
     HIPCHK(hipMalloc((void **)&d_rp, sizeof(float) * 3 * F));
     HIPCHK(hipMalloc((void **)&d_rr, sizeof(float) * 4 * F));
     HIPCHK(hipMalloc((void **)&d_jr, sizeof(float) * 4 * J * F));
@@ -1584,8 +1646,14 @@ static int launch_dynamics(ParcEnv *e, const float *action_dev, hipStream_t st) 
 static int launch_curriculum(ParcEnv *e, hipStream_t st) {
     hipLaunchKernelGGL(k_done_scatter, dim3(e->nchunks), dim3(1024), 0, st, e->d_ema, e->sp.buf.motion_ids, e->N, e->d_done_list,
                        e->d_done_key, e->d_reset_count, e->sp.never_done);
-    hipLaunchKernelGGL(k_fail_rate_ema, dim3(e->M), dim3(1024), 0, st, e->d_done_key, e->d_reset_count, e->d_fail, e->M,
-                       e->cfg.fail_rate_ema_weight);
+    if (e->M <= 64 && !e->force_ema_leader) {
+        hipLaunchKernelGGL(k_fail_rate_ema, dim3(e->M), dim3(1024), 0, st, e->d_done_key, e->d_reset_count, e->d_fail, e->M,
+                           e->cfg.fail_rate_ema_weight);
+    } else { // d_motion_done doubles as the per-motion "first list entry" slot (INT_MAX between steps)
+        hipLaunchKernelGGL(k_ema_first, dim3((e->N + 255) / 256), dim3(256), 0, st, e->d_done_key, e->d_reset_count, e->d_motion_done);
+        hipLaunchKernelGGL(k_ema_leader, dim3((e->N + 3) / 4), dim3(256), 0, st, e->d_done_key, e->d_reset_count, e->d_motion_done, e->d_fail,
+                           e->cfg.fail_rate_ema_weight);
+    }
     HIPCHK(hipGetLastError());
     return PARC_OK;
 }

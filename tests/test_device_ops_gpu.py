@@ -227,3 +227,33 @@ def test_never_done_and_consumed_reset_list(tmp_path):
     fr, seen = run(False)
     assert seen > 50
     assert (fr_nd < 1.0).any()   # the EMA ran although no flag was raised
+
+
+def test_large_library_ema_path_equals_the_per_motion_chain(tmp_path, monkeypatch):
+    """Libraries of thousands of motions update the fail rates with one leader thread per motion that finished an env
+    (k_ema_first / k_ema_leader) instead of one block per motion; both apply the reference's sequential chain
+    (dm_env.py:646-660) in env order, so the tables must be bit-identical."""
+    import torch
+    from gpu_helpers import default_config, write_motion_yaml
+    from helpers import CLIPS4
+    from parc_amd.envs.hip_parkour_env import HipParkourEnv
+    n = 8192
+    cfg = default_config()
+    cfg["env"]["dm"]["motion_file"] = write_motion_yaml(tmp_path, CLIPS4, [1, 1, 1, 1])
+    envs = []
+    for leader in (False, True):
+        if leader:
+            monkeypatch.setenv("PARC_EMA_LEADER", "1")
+        envs.append(HipParkourEnv(cfg, n, "cuda:0", False, seed=4))
+        monkeypatch.delenv("PARC_EMA_LEADER", raising=False)
+    for env in envs:
+        env.reset()
+    g = torch.Generator(device="cuda:0"); g.manual_seed(9)
+    for s in range(25):
+        drift = 0.06 * torch.randn(envs[0]._char_root_pos.shape, device="cuda:0", generator=g)
+        for env in envs:
+            env._char_root_pos += drift
+            env.step(None); env.reset_done()
+        fa, fb = envs[0].get_fail_rates().numpy(), envs[1].get_fail_rates().numpy()
+        assert np.array_equal(fa, fb), (s, fa, fb)
+    assert (fa < 1.0).all() and torch.equal(envs[0]._motion_ids, envs[1]._motion_ids)

@@ -11,6 +11,12 @@ steps = int(os.environ.get("KB_STEPS", "100"))
 sys.stdout = sys.stderr
 cfg = path_loader.load_config("data/configs/tracker_config/dm_env_default.yaml")
 dyn = os.environ.get("KB_DYN", "1") == "1"
+if int(os.environ.get("KB_MOTIONS", "0")) > 0:  # synthetic library (cfg 3 / 5)
+    import tempfile
+    from parc_amd.util import synth_dataset
+    base = str(path_loader.resolve_path(cfg["env"]["dm"]["motion_file"]))
+    cfg["env"]["dm"]["motion_file"] = synth_dataset.write_spec(os.path.join(tempfile.mkdtemp(), "motions.yaml"), base,
+                                                               int(os.environ["KB_MOTIONS"]), yaw=os.environ.get("KB_YAW", "0") == "1")
 env = HipParkourEnv(cfg, n, "cuda:0", False, seed=1234, mirror_ref_state=False, enable_dynamics=dyn)
 env.reset()
 lo, hi = env._action_bound_low, env._action_bound_high
