@@ -156,7 +156,7 @@ inline bool build_wave_tables(const DynModel &M, const CoopTables &C, WaveTables
 // Even slots = work segments, odd slots = the barrier wait that follows (see the WSTAMP calls in the substep loop).
 #ifdef PARC_STAMPS
 __device__ unsigned long long g_wave_stamps[4][16];
-__device__ unsigned long long g_wave_cnt[16][8]; // per body: lanes, near lanes, waves with a near lane, hit lanes, hit bits, slow lanes, pass-2 iterations, waves
+__device__ unsigned long long g_wave_cnt[16][8]; // filled by -DPARC_COUNTS builds only: // per body: lanes, near lanes, waves with a near lane, hit lanes, hit bits, slow lanes, pass-2 iterations, waves
 #define WSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); wacc[i] += t_ - wlast; wlast = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
 // pin: the 27 values of (IA, pA) must be complete before the stamp that follows (keeps arithmetic from sinking past it)
 #define WPIN(IA_, pA_) do { for (int i_ = 0; i_ < 21; ++i_) asm volatile("" : "+v"((IA_).s[i_])); for (int i_ = 0; i_ < 6; ++i_) asm volatile("" : "+v"((pA_).a[i_])); } while (0)
@@ -360,7 +360,7 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
 #ifdef WV_EXP_NOSLOW
     slow = false;
 #endif
-#ifdef PARC_STAMPS
+#ifdef PARC_COUNTS
     {
         const unsigned long long m_near = __ballot(hmax > -1.0e38f), m_hit = __ballot(hit != 0u && !slow), m_slow = __ballot(slow);
         int bits = __popc(slow ? 0u : hit);
