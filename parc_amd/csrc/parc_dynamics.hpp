@@ -272,6 +272,11 @@ PARC_HD float own_column_contact(const DynTerrain &T, v3 s, float r, int ix, int
     const float ex = s.x - (T.min_x + (float)ix * T.dx), ey = s.y - (T.min_y + (float)iy * T.dy);
     const float hx = 0.5f * T.dx, hy = 0.5f * T.dy;
     float pen = best;
+    {   // a side exit costs at least the distance to the nearest face: farther from every face than it is deep -> up, and the
+        // neighbour heights need not be looked at (the usual case: a foot corner a few millimetres into the ground)
+        const float dx_ = hx - (ex < 0.f ? -ex : ex), dy_ = hy - (ey < 0.f ? -ey : ey);
+        if ((dx_ < dy_ ? dx_ : dy_) >= best) return pen + r;
+    }
     PARC_UNROLL
     for (int f = 0; f < 4; ++f) {
         const int ox = f == 0 ? 1 : (f == 1 ? -1 : 0), oy = f == 2 ? 1 : (f == 3 ? -1 : 0);

@@ -77,7 +77,12 @@ struct WaveTables {
 #define WV_OFF_PMAX (WV_OFF_PATCH + DYN_PATCH * DYN_PATCH * 64)
 #define WV_OFF_PMAX3 (WV_OFF_PMAX + WV_PI * WV_PI * 64)
 #define WV_OFF_ROOTI (WV_OFF_PMAX3 + WV_P3 * WV_P3 * 64)
-#define WV_OFF_FLAG (WV_OFF_ROOTI + 2 * 30 * 64)   // one word: "the helper has published trunk position 1 for substep n"
+#define WV_OFF_FLAG (WV_OFF_ROOTI + 2 * 30 * 64)   // hand-off flags between the waves of a block (see WV_F_*)
+// A flag holds the number of substeps for which its producer has published: a consumer of substep `sub` waits for > sub.
+#define WV_F_KIN(slot) (12 + (slot)) // wave 0: kinematics of attach slot (0..2) (+ the root position, with the root body's slot)
+#define WV_F_UP(lc) (lc)      // limb chain lc (1..4): its articulated inertia / bias handed to the trunk
+#define WV_F_REC(k) (5 + (k)) // helper wave: own inertia + contacts of trunk position k (0, 1)
+#define WV_F_ACC(slot) (8 + (slot)) // wave 0: spatial acceleration of attach slot (0..2)
 #define WV_OFF_FAC (WV_OFF_FLAG + 64)
 #define WV_LDS_FLOATS_MAX (WV_OFF_FAC + (1 + WV_MAXLIMB) * WV_MAXLEN * WV_FAC * 64)
 inline int wv_lds_floats(int fac_total) { return WV_OFF_FAC + fac_total * 64; } // the factor region is last and packed
@@ -402,11 +407,9 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
             }
             const float ex = g.x - (Tp.min_x + (float)pa_ * Tp.dx), ey = g.y - (Tp.min_y + (float)pb_ * Tp.dy);
             const float lim = rad + 1e-3f; // slack >> the rounding of the cell centres: it only admits candidates
-#ifdef WV_EXP_NONEIGH
-            const bool nx = false, ny = false;
-#else
-            const bool nx = hx - fabsf(ex) < lim, ny = hy - fabsf(ey) < lim;
-#endif
+            // (a point of radius 0 -- a box corner -- cannot touch a neighbour column at all: pen = -distance.  `rad` is
+            // wave-uniform, so the whole neighbour block is a scalar branch for the 16 foot corners)
+            const bool nx = rad > 0.f && hx - fabsf(ex) < lim, ny = rad > 0.f && hy - fabsf(ey) < lim;
             if (nx || ny) {
                 const int sx = ex >= 0.f ? 1 : -1, sy = ey >= 0.f ? 1 : -1;
                 for (int c = 0; c < 3; ++c) { // x side, y side, diagonal
@@ -633,7 +636,7 @@ __global__ __launch_bounds__(256, 1) WV_EXTRA_ATTR void k_dynamics_wave(const Dy
     float *s_rootp = smem + WV_OFF_ROOTP + lane, *s_patch = smem + WV_OFF_PATCH + lane, *s_pmax = smem + WV_OFF_PMAX + lane;
     float *s_fac = smem + WV_OFF_FAC + lane, *s_rooti = smem + WV_OFF_ROOTI + lane, *s_pmax3 = smem + WV_OFF_PMAX3 + lane;
     volatile int *s_flag = reinterpret_cast<volatile int *>(smem + WV_OFF_FLAG);
-    if (threadIdx.x == 0) *s_flag = 0; // published before the first barrier below
+    if (threadIdx.x < 16) s_flag[threadIdx.x] = 0; // published before the first barrier below
 
     const float *dp = buf.char_dof_pos + (size_t)D_ * ec, *dv = buf.char_dof_vel + (size_t)D_ * ec, *ac = action + (size_t)D_ * ec;
     WvBody limb[WV_MAXLEN], trunk[WV_MAXLEN];
@@ -723,33 +726,52 @@ __global__ __launch_bounds__(256, 1) WV_EXTRA_ATTR void k_dynamics_wave(const Dy
     __syncthreads();
 
     WSTAMP(0); // prologue: state load, height patch, running max
-    for (int sub = 0; sub < nsub; ++sub) {
-        // ---- phase 1: trunk kinematics (wave 0) -------------------------------------------------------------------------
-        if (w == 0) {
-            s_rootp[0] = rp.x; s_rootp[64] = rp.y; s_rootp[128] = rp.z;
-            q4 pq = rq; v3 pr = mk(0.f, 0.f, 0.f); s6 pv = s6mk(rw, rv);
-            PARC_UNROLL
-            for (int k = 0; k < WV_MAXLEN; ++k) {
-                if (k < tlen) {
-                    wv_fk_body(M, W, W.body[0][k], trunk[k], pq, pr, pv);
-                    const int slot = W.att_slot[k];
-                    if (slot >= 0) {
-                        float *s = s_attkin + slot * 13 * 64;
-                        s[0] = pq.x; s[64] = pq.y; s[128] = pq.z; s[192] = pq.w; s[256] = pr.x; s[320] = pr.y; s[384] = pr.z;
-                        PARC_UNROLL
-                        for (int a = 0; a < 6; ++a) s[(7 + a) * 64] = pv.a[a];
-                    }
+    // ---- substeps.  The four waves of a block meet at NO barrier inside the loop: every hand-off is a record in LDS plus a
+    // flag (the producer writes the record, then the flag: LDS operations of one wave complete in order; the consumer polls
+    // the flag, then reads).  A wave waits only for what it really depends on:
+    //   limbs:  attach kinematics (wave 0)  ->  kinematics, inward pass, hand-over  ->  attach acceleration (wave 0)  ->  outward pass
+    //   wave 0: trunk kinematics -> its own limb -> upper trunk (waits for the limbs hanging there and for the helper's records)
+    //           -> root solve (waits for the limbs hanging off the root) -> trunk outward -> NEXT substep's trunk kinematics
+    //           -> its own limb's outward pass (moved behind the next kinematics: the other limbs wait for that, not for this)
+    // Re-use of a record by the next substep is ordered by the same chain (e.g. a limb overwrites its hand-over only after
+    // it has received the acceleration that wave 0 computed from the previous one).
+    auto publish = [&](int f, int sub) __attribute__((always_inline)) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) s_flag[f] = sub + 1;
+    };
+    auto await = [&](int f, int sub) __attribute__((always_inline)) {
+        int spins = 0;
+        while (s_flag[f] <= sub && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(2); // bounded: a protocol error must not hang the GPU
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    auto trunk_kinematics = [&](int sub) __attribute__((always_inline)) { // wave 0
+        s_rootp[0] = rp.x; s_rootp[64] = rp.y; s_rootp[128] = rp.z;
+        q4 pq = rq; v3 pr = mk(0.f, 0.f, 0.f); s6 pv = s6mk(rw, rv);
+        PARC_UNROLL
+        for (int k = 0; k < WV_MAXLEN; ++k) {
+            if (k < tlen) {
+                wv_fk_body(M, W, W.body[0][k], trunk[k], pq, pr, pv);
+                const int slot = W.att_slot[k];
+                if (slot >= 0) {
+                    float *s = s_attkin + slot * 13 * 64;
+                    s[0] = pq.x; s[64] = pq.y; s[128] = pq.z; s[192] = pq.w; s[256] = pr.x; s[320] = pr.y; s[384] = pr.z;
+                    PARC_UNROLL
+                    for (int a = 0; a < 6; ++a) s[(7 + a) * 64] = pv.a[a];
+                    publish(WV_F_KIN(slot), sub);
                 }
             }
         }
-        WSTAMP(1);
-        __syncthreads();
+    };
+    if (w == 0) trunk_kinematics(0);
+    WSTAMP(1);
+    for (int sub = 0; sub < nsub; ++sub) {
+        if (w != 0) { // the root position travels with the root body's slot; a limb also needs its own parent's slot
+            if (W.att_slot[0] >= 0) await(WV_F_KIN(W.att_slot[0]), sub);
+            if (has_limb) await(WV_F_KIN(W.par_slot[lc]), sub);
+        }
         WSTAMP(2);
         const v3 rootp = mk(s_rootp[0], s_rootp[64], s_rootp[128]);
-        // ---- phase 2: inward pass.  Limbs that hang off the upper trunk ("early": the arms) run completely in part A;
-        // limbs that hang off the root body ("late": the legs) do their tip body there (the foot, usually the one with
-        // contacts).  In part B wave 0 eliminates the non-root trunk bodies (head, torso: they need only the early limbs)
-        // while the late limbs finish; the root body follows after the next barrier.
+        // ---- inward pass of this wave's limb -----------------------------------------------------------------------------
         sym6 Icl; s6 pcl = s6zero();   // carry of this wave's limb
         PARC_UNROLL
         for (int i = 0; i < 21; ++i) Icl.s[i] = 0.f;
@@ -764,14 +786,7 @@ __global__ __launch_bounds__(256, 1) WV_EXTRA_ATTR void k_dynamics_wave(const Dy
             WPIN(Icl, pcl);
             WSTAMP(14);
         };
-        auto limb_handover = [&]() __attribute__((always_inline)) {
-            float *u = s_up + (lc - 1) * 27 * 64;
-            PARC_UNROLL
-            for (int i = 0; i < 21; ++i) u[i * 64] = Icl.s[i];
-            PARC_UNROLL
-            for (int a = 0; a < 6; ++a) u[(21 + a) * 64] = pcl.a[a];
-        };
-        if (has_limb) { // part A
+        if (has_limb) {
             const float *s = s_attkin + W.par_slot[lc] * 13 * 64;
             q4 pq; pq.x = s[0]; pq.y = s[64]; pq.z = s[128]; pq.w = s[192];
             v3 pr = mk(s[256], s[320], s[384]);
@@ -782,92 +797,21 @@ __global__ __launch_bounds__(256, 1) WV_EXTRA_ATTR void k_dynamics_wave(const Dy
             for (int k = 0; k < WV_MAXLEN; ++k) if (k < llen) wv_fk_body(M, W, W.body[lc][k], limb[k], pq, pr, pv);
             WSTAMP(11);
             PARC_UNROLL
-            for (int k = WV_MAXLEN - 1; k >= 0; --k)
-                if (k < llen && (early || k == llen - 1)) limb_body(k);
-            if (early || llen == 1) limb_handover();
-        }
-        WSTAMP(3);
-        __syncthreads();
-        WSTAMP(4);
-        sym6 Ict; s6 pct = s6zero();   // carry of the trunk
-        PARC_UNROLL
-        for (int i = 0; i < 21; ++i) Ict.s[i] = 0.f;
-        s6 acc_root = s6zero();
-        auto trunk_body = [&](int k) __attribute__((always_inline)) {
-            const int b = W.body[0][k];
-            const m3 R = qmat(trunk[k].bq);
-            sym6 IA = Ict; s6 pA = pct;
-            if (W.prep[k]) { // prepared by the helper wave during part B
-                if (k > 0) { // the root's record is covered by the barrier before phase 3; position 1 is published through the flag
-                    while (*s_flag < sub + 1) __builtin_amdgcn_s_sleep(4);
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                }
-                const float *sr = s_rooti + k * 30 * 64;
-                PARC_UNROLL
-                for (int i = 0; i < 21; ++i) IA.s[i] += sr[i * 64];
-                PARC_UNROLL
-                for (int a = 0; a < 6; ++a) pA.a[a] += sr[(21 + a) * 64];
-                trunk[k].fcon = mk(sr[27 * 64], sr[28 * 64], sr[29 * 64]);
-            } else {
-                WSTAMP(15);
-                wv_body_inertia(M, W, T, X, b, trunk[k], R, rootp, IA, pA WSTAMP_ARGS);
-            }
-            for (int ci = 0; ci < W.nchild[k]; ++ci) {
-                const float *u = s_up + (W.child[k][ci] - 1) * 27 * 64;
-                PARC_UNROLL
-                for (int i = 0; i < 21; ++i) IA.s[i] += u[i * 64];
-                PARC_UNROLL
-                for (int a = 0; a < 6; ++a) pA.a[a] += u[(21 + a) * 64];
-            }
-            if (b == 0) { // floating base: solve IA a0 = -pA (Cholesky)
-                float Lm[6][6];
-                PARC_UNROLL
-                for (int j = 0; j < 6; ++j) {
-                    float sd = sget(IA, j, j);
-                    PARC_UNROLL
-                    for (int q = 0; q < j; ++q) sd -= Lm[j][q] * Lm[j][q];
-                    sd = sd > 1e-12f ? DYN_SQRT(sd) : 1e-6f;
-                    const float isd = DYN_RCP(sd);
-                    PARC_UNROLL
-                    for (int a = j + 1; a < 6; ++a) {
-                        float sa = sget(IA, a, j);
-                        PARC_UNROLL
-                        for (int q = 0; q < j; ++q) sa -= Lm[a][q] * Lm[j][q];
-                        Lm[a][j] = sa * isd;
-                    }
-                    Lm[j][j] = isd; // the reciprocal of the pivot
-                }
-                float y[6], xs[6];
-                PARC_UNROLL
-                for (int a = 0; a < 6; ++a) {
-                    float sa = -pA.a[a];
-                    PARC_UNROLL
-                    for (int q = 0; q < a; ++q) sa -= Lm[a][q] * y[q];
-                    y[a] = sa * Lm[a][a];
-                }
-                PARC_UNROLL
-                for (int a_ = 0; a_ < 6; ++a_) {
-                    const int a = 5 - a_;
-                    float sa = y[a];
-                    PARC_UNROLL
-                    for (int q = a + 1; q < 6; ++q) sa -= Lm[q][a] * xs[q];
-                    xs[a] = sa * Lm[a][a];
-                }
-                PARC_UNROLL
-                for (int a = 0; a < 6; ++a) acc_root.a[a] = xs[a];
-            } else {
-                wv_joint_inward(M, W, b, trunk[k], R, dt, IA, pA, Ict, pct, s_fac + W.fac_off[0][k] * 64);
-            }
-        };
-        if (w == 0) { // part B, trunk: every body but the root
+            for (int k = WV_MAXLEN - 1; k >= 0; --k) if (k < llen) limb_body(k);
+            float *u = s_up + (lc - 1) * 27 * 64;
             PARC_UNROLL
-            for (int k = WV_MAXLEN - 1; k >= 1; --k) if (k < tlen) trunk_body(k);
+            for (int i = 0; i < 21; ++i) u[i * 64] = Icl.s[i];
+            PARC_UNROLL
+            for (int a = 0; a < 6; ++a) u[(21 + a) * 64] = pcl.a[a];
+            if (w != 0) publish(WV_F_UP(lc), sub); // wave 0 consumes its own limb's record in program order
         }
-        if (w == W.helper) { // part B, helper: own inertia + contacts of the trunk bodies that carry limbs (their kinematics are in the
-                             // attach slots).  Position 1 first: wave 0 needs it as soon as it is through with the bodies above.
+        // ---- helper wave: own inertia + contacts of the trunk bodies that carry limbs (their kinematics are in the attach
+        // slots).  Position 1 first: wave 0 needs it as soon as it is through with its limb and the bodies above.
+        if (w == W.helper) {
             PARC_UNROLL
             for (int k = 1; k >= 0; --k) {
                 if (!W.prep[k]) continue;
+                await(WV_F_KIN(W.att_slot[k]), sub);
                 const float *s = s_attkin + W.att_slot[k] * 13 * 64;
                 WvBody rb;
                 rb.bq.x = s[0]; rb.bq.y = s[64]; rb.bq.z = s[128]; rb.bq.w = s[192];
@@ -885,23 +829,84 @@ __global__ __launch_bounds__(256, 1) WV_EXTRA_ATTR void k_dynamics_wave(const Dy
                 PARC_UNROLL
                 for (int a = 0; a < 6; ++a) sr[(21 + a) * 64] = pA.a[a];
                 sr[27 * 64] = rb.fcon.x; sr[28 * 64] = rb.fcon.y; sr[29 * 64] = rb.fcon.z;
-                if (k > 0) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // LDS writes of this wave complete in order; this keeps the compiler in line
-                    if (lane == 0) *s_flag = sub + 1;
-                }
+                publish(WV_F_REC(k), sub);
             }
         }
-        if (has_limb && !early && llen > 1) { // part B, late limbs: the rest of the chain
-            PARC_UNROLL
-            for (int k = WV_MAXLEN - 2; k >= 0; --k) if (k < llen - 1) limb_body(k);
-            limb_handover();
-        }
-        WSTAMP(5);
-        __syncthreads();
-        WSTAMP(6);
-        // ---- phase 3: root body, floating-base solve, trunk outward, trunk/root integration (wave 0) ------------------
+        WSTAMP(3);
+        // ---- wave 0: trunk inward pass, floating-base solve, trunk outward pass, integration -----------------------------
         if (w == 0) {
-            trunk_body(0);
+            sym6 Ict; s6 pct = s6zero();   // carry of the trunk
+            PARC_UNROLL
+            for (int i = 0; i < 21; ++i) Ict.s[i] = 0.f;
+            s6 acc_root = s6zero();
+            auto trunk_body = [&](int k) __attribute__((always_inline)) {
+                const int b = W.body[0][k];
+                const m3 R = qmat(trunk[k].bq);
+                sym6 IA = Ict; s6 pA = pct;
+                if (W.prep[k]) { // prepared by the helper wave
+                    await(WV_F_REC(k), sub);
+                    const float *sr = s_rooti + k * 30 * 64;
+                    PARC_UNROLL
+                    for (int i = 0; i < 21; ++i) IA.s[i] += sr[i * 64];
+                    PARC_UNROLL
+                    for (int a = 0; a < 6; ++a) pA.a[a] += sr[(21 + a) * 64];
+                    trunk[k].fcon = mk(sr[27 * 64], sr[28 * 64], sr[29 * 64]);
+                } else {
+                    WSTAMP(15);
+                    wv_body_inertia(M, W, T, X, b, trunk[k], R, rootp, IA, pA WSTAMP_ARGS);
+                }
+                for (int ci = 0; ci < W.nchild[k]; ++ci) {
+                    const int c = W.child[k][ci];
+                    if (c != lc) await(WV_F_UP(c), sub);
+                    const float *u = s_up + (c - 1) * 27 * 64;
+                    PARC_UNROLL
+                    for (int i = 0; i < 21; ++i) IA.s[i] += u[i * 64];
+                    PARC_UNROLL
+                    for (int a = 0; a < 6; ++a) pA.a[a] += u[(21 + a) * 64];
+                }
+                if (b == 0) { // floating base: solve IA a0 = -pA (Cholesky)
+                    float Lm[6][6];
+                    PARC_UNROLL
+                    for (int j = 0; j < 6; ++j) {
+                        float sd = sget(IA, j, j);
+                        PARC_UNROLL
+                        for (int q = 0; q < j; ++q) sd -= Lm[j][q] * Lm[j][q];
+                        sd = sd > 1e-12f ? DYN_SQRT(sd) : 1e-6f;
+                        const float isd = DYN_RCP(sd);
+                        PARC_UNROLL
+                        for (int a = j + 1; a < 6; ++a) {
+                            float sa = sget(IA, a, j);
+                            PARC_UNROLL
+                            for (int q = 0; q < j; ++q) sa -= Lm[a][q] * Lm[j][q];
+                            Lm[a][j] = sa * isd;
+                        }
+                        Lm[j][j] = isd; // the reciprocal of the pivot
+                    }
+                    float y[6], xs[6];
+                    PARC_UNROLL
+                    for (int a = 0; a < 6; ++a) {
+                        float sa = -pA.a[a];
+                        PARC_UNROLL
+                        for (int q = 0; q < a; ++q) sa -= Lm[a][q] * y[q];
+                        y[a] = sa * Lm[a][a];
+                    }
+                    PARC_UNROLL
+                    for (int a_ = 0; a_ < 6; ++a_) {
+                        const int a = 5 - a_;
+                        float sa = y[a];
+                        PARC_UNROLL
+                        for (int q = a + 1; q < 6; ++q) sa -= Lm[q][a] * xs[q];
+                        xs[a] = sa * Lm[a][a];
+                    }
+                    PARC_UNROLL
+                    for (int a = 0; a < 6; ++a) acc_root.a[a] = xs[a];
+                } else {
+                    wv_joint_inward(M, W, b, trunk[k], R, dt, IA, pA, Ict, pct, s_fac + W.fac_off[0][k] * 64);
+                }
+            };
+            PARC_UNROLL
+            for (int k = WV_MAXLEN - 1; k >= 0; --k) if (k < tlen) trunk_body(k);
+            WSTAMP(5);
             s6 ap = acc_root;
             PARC_UNROLL
             for (int k = 0; k < WV_MAXLEN; ++k) {
@@ -909,32 +914,42 @@ __global__ __launch_bounds__(256, 1) WV_EXTRA_ATTR void k_dynamics_wave(const Dy
                     const int b = W.body[0][k];
                     if (b != 0) wv_joint_outward(M, W, b, trunk[k], ap, s_fac + W.fac_off[0][k] * 64);
                     const int slot = W.att_slot[k];
-                    if (slot >= 0) {
+                    if (slot >= 0) { // the limbs hanging here can start their outward pass
                         PARC_UNROLL
                         for (int a = 0; a < 6; ++a) s_attacc[(slot * 6 + a) * 64] = ap.a[a];
+                        publish(WV_F_ACC(slot), sub);
+                    }
+                    if (k == 0) { // integrate the root at once: the limbs that hang off it (the long chains) then have the next
+                                  // substep's kinematics of their parent before the trunk's outward pass and integration are through
+                        const v3 alpha = s6ang(acc_root), aO = s6lin(acc_root);
+                        const v3 rv_new = rv + dt * (aO + cross(rw, rv));
+                        v3 rw_new = rw + dt * alpha;
+                        rw_new = DYN_RCP(1.f + dt * M.ang_damping) * rw_new;
+                        const float wm = DYN_SQRT(dot(rw_new, rw_new));
+                        if (wm > M.max_ang_vel) rw_new = (M.max_ang_vel * DYN_RCP(wm)) * rw_new;
+                        rv = rv_new; rw = rw_new;
+                        rp = rp + dt * rv;
+                        rq = qnormalize(qmul(qexp(dt * rw), rq));
+                        if (slot >= 0 && sub + 1 < nsub) {
+                            s_rootp[0] = rp.x; s_rootp[64] = rp.y; s_rootp[128] = rp.z;
+                            float *s = s_attkin + slot * 13 * 64;
+                            s[0] = rq.x; s[64] = rq.y; s[128] = rq.z; s[192] = rq.w; s[256] = 0.f; s[320] = 0.f; s[384] = 0.f;
+                            s[448] = rw.x; s[512] = rw.y; s[576] = rw.z; s[640] = rv.x; s[704] = rv.y; s[768] = rv.z;
+                            publish(WV_F_KIN(slot), sub + 1);
+                        }
                     }
                 }
             }
-            // root + trunk joints
-            {
-                const v3 alpha = s6ang(acc_root), aO = s6lin(acc_root);
-                const v3 rv_new = rv + dt * (aO + cross(rw, rv));
-                v3 rw_new = rw + dt * alpha;
-                rw_new = DYN_RCP(1.f + dt * M.ang_damping) * rw_new;
-                const float wm = DYN_SQRT(dot(rw_new, rw_new));
-                if (wm > M.max_ang_vel) rw_new = (M.max_ang_vel * DYN_RCP(wm)) * rw_new;
-                rv = rv_new; rw = rw_new;
-                rp = rp + dt * rv;
-                rq = qnormalize(qmul(qexp(dt * rw), rq));
-            }
             PARC_UNROLL
             for (int k = 0; k < WV_MAXLEN; ++k) if (k < tlen) wv_integrate_joint(M, W, W.body[0][k], trunk[k], dt);
+            WSTAMP(7);
+            if (sub + 1 < nsub) trunk_kinematics(sub + 1); // before this wave's own outward pass: the other limbs wait for it
+            WSTAMP(1);
         }
-        WSTAMP(7);
-        __syncthreads();
-        WSTAMP(8);
-        // ---- phase 4: limb outward pass + integration (all waves) -------------------------------------------------------
+        // ---- outward pass + integration of this wave's limb ----------------------------------------------------------------
         if (has_limb) {
+            if (w != 0) await(WV_F_ACC(W.par_slot[lc]), sub);
+            WSTAMP(8);
             s6 ap;
             PARC_UNROLL
             for (int a = 0; a < 6; ++a) ap.a[a] = s_attacc[(W.par_slot[lc] * 6 + a) * 64];
