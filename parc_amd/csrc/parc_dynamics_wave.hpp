@@ -216,13 +216,6 @@ __device__ __forceinline__ void wv_fk_body(const DynModel &M, const WaveTables &
     B.bq = pq; B.r = pr; B.vel = pv; B.cJ = cJ;
 }
 
-#ifndef WV_PASS1_UNROLL
-#define WV_PASS1_UNROLL _Pragma("unroll 4")
-#endif
-
-#ifndef WV_EXTRA_ATTR
-#define WV_EXTRA_ATTR
-#endif
 
 struct WvCtx { // per-lane constants of the control step
     const float *s_patch, *s_pmax, *s_pmax3; // + lane
@@ -310,9 +303,6 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
             if (cb.z + rootp.z - brho > hmax) hmax = -3.0e38f; // clears everything: no point survives the test below
         }
     }
-#ifdef WV_EXP_NOCONTACT
-    hmax = -3.0e38f;
-#endif
     // Narrow phase in two passes.  A sphere can only touch the column of its own cell and the columns of the neighbours on
     // the sides whose face is closer than its radius (for rad < half a cell: at most the x-side, the y-side and their
     // diagonal; the far sides are at least half a cell away).
@@ -362,9 +352,6 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
             c0 = n0; c1 = n1;
         }
     }
-#ifdef WV_EXP_NOSLOW
-    slow = false;
-#endif
 #ifdef PARC_COUNTS
     {
         const unsigned long long m_near = __ballot(hmax > -1.0e38f), m_hit = __ballot(hit != 0u && !slow), m_slow = __ballot(slow);
@@ -381,9 +368,6 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
     }
 #endif
     if (slow) hit = 0u;
-#ifdef WV_EXP_NOPASS2
-    hit = 0u;
-#endif
     for (int pi = 0; pi < npt; ++pi) {
         const bool mine = (hit >> pi) & 1u;
         if (!__any(mine)) continue; // uniform
@@ -612,7 +596,7 @@ __device__ __forceinline__ void wv_store_joint(const DynModel &M, const WaveTabl
     cf[3 * b] = fc.x; cf[3 * b + 1] = fc.y; cf[3 * b + 2] = fc.z;
 }
 
-__global__ __launch_bounds__(256, 1) WV_EXTRA_ATTR void k_dynamics_wave(const DynModel *__restrict__ Mp, const WaveTables *__restrict__ Wp, DynTerrain T,
+__global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__restrict__ Mp, const WaveTables *__restrict__ Wp, DynTerrain T,
                                                           ParcEnvBuffers buf, const float *__restrict__ action,
                                                           const float *__restrict__ env_off_all, float *__restrict__ root_shadow, int N) {
     extern __shared__ float smem[];
