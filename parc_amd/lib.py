@@ -93,6 +93,7 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the env step.")
+    import torch  # noqa: F401  the process must hold ONE HIP runtime (torch's): load it before the library binds to libamdhip64
     lib = C.CDLL(LIB_PATH)
     lib.parc_build_flags.restype = C.c_char_p
     flags = lib.parc_build_flags().decode()
