@@ -315,3 +315,29 @@ def test_far_envs_integrate_as_precisely_as_near_ones(monkeypatch):
     assert abs(near - expect) < 0.05 * expect
     assert abs(far - expect) < 0.05 * expect + 6.1e-5           # one rounding of the buffer value itself
     assert abs(before[1] - expect) > abs(far - expect)         # the per-step rounding this removes (DESIGN.md quotes the numbers)
+
+
+def test_bench_launches_its_own_ranks_on_the_gpu():
+    """`python bench.py --gpus 2` end to end on hardware: the launcher starts two fresh ranks (both on this box's one GPU:
+    PARC_BENCH_SHARE_GPU, gloo for the barrier / max), each owns 4 096 of 8 192 envs (strong scaling) with the env origins of
+    its global index range, rank 0 prints exactly one JSON line with the contract's fields."""
+    import json
+    import subprocess
+    import sys
+    from conftest import REPO
+    env = dict(os.environ, PARC_BENCH_SHARE_GPU="1")
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None)
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--envs", "8192", "--steps", "20", "--warmup", "5",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 20 and d["vs_baseline"] is None and d["dtype"] == "f32"
+    assert d["config"]["total_envs"] == 8192 and d["config"]["envs_per_gpu"] == 4096 and "workload" in d["config"]
+    assert abs(d["value"] - 8192 * 20 / (d["ms_per_step"] * 20e-3)) < 1e-6 * d["value"]
+    assert d["roofline"]["kernel"] == "k_dynamics_wave" and d["roofline"]["kernel_ms"] > 0 and 0 < d["roofline"]["frac"] < 1
+    assert 1e6 < d["value"] < 1e9
