@@ -160,9 +160,57 @@ def cpu_baseline(env, seconds, dynamics_on, actions):
         st["timestep_buf"][:] = steps % 8  # stay inside the clips
         run_step(); steps += 1
     dt = time.time() - t0
+    out = {"value": n * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+           "sample": f"{steps} {'full (dynamics + obs/reward/done)' if dynamics_on else 'kinematic'} steps x {n} envs, C/C++ oracle "
+                     "(scalar, -O2, one thread per core), same scene and state"}
+    try:
+        out["torch_path"] = torch_path_baseline(env, max(3.0, 0.5 * seconds), st)
+    except Exception as ex:  # a baseline leg must never take the benchmark down
+        out["torch_path"] = {"error": repr(ex)}
+    return out
+
+
+def torch_path_baseline(env, seconds, st):
+    """The north star's "reference CPU-PyTorch motion_lib / kin_char_model path": oracle/torch_path.py issues the reference's batched
+    tensor-op sequence (calc_motion_frame at t and the six look-ahead times, dof <-> rot, the three FK calls of a step) on CPU
+    tensors with all host cores.  Pinned against the reference's golden vectors by tests/test_oracle_golden.py."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    from oracle import torch_path as tp
+    from conftest import golden
+    from parc_amd import lib as L
+    cg = golden("char_model")
+    cm = tp.CharModel(cg["parent"], cg["local_translation"], cg["local_rotation"], cg["joint_type"], cg["joint_axis"], cg["dof_idx"], int(cg["dof_size"]))
+    sc = env._scene
+    clips = sc.clips
+    F = sum(c.num_frames for c in clips)
+    rv, rav, dv = np.zeros((F, 3), np.float32), np.zeros((F, 3), np.float32), np.zeros((F, 28), np.float32)
+    L.check(env._lib.parc_env_get_frame_vel_tables(env._handle, L.np_f32p(rv), L.np_f32p(rav), L.np_f32p(dv)))
+    nf = np.array([c.num_frames for c in clips], np.int64)
+    tables = dict(frame_root_pos=np.concatenate([c.root_pos for c in clips]), frame_root_rot=np.concatenate([c.root_rot for c in clips]),
+                  frame_joint_rot=np.concatenate([c.joint_rot for c in clips]), frame_root_vel=rv, frame_root_ang_vel=rav, frame_dof_vel=dv,
+                  frame_contacts=np.concatenate([c.contacts if c.contacts is not None else np.zeros((c.num_frames, 15), np.float32) for c in clips]),
+                  motion_num_frames=nf, motion_lengths=np.array([(c.num_frames - 1) / c.fps for c in clips], np.float32),
+                  motion_loop_modes=np.array([c.loop_mode for c in clips], np.int64), motion_start_idx=np.concatenate([[0], np.cumsum(nf)[:-1]]),
+                  motion_root_pos_delta=np.stack([np.append(c.root_pos[-1, :2] - c.root_pos[0, :2], 0.0) for c in clips]).astype(np.float32))
+    lib = tp.MotionLib(tables)
+    cores = max(1, min(os.cpu_count() or 1, 64))
+    torch.set_num_threads(cores)
+    n = env.get_num_envs()
+    ids = torch.as_tensor(st["motion_ids"].astype(np.int64))
+    times = torch.as_tensor(st["time_offsets"].astype(np.float32))
+    crp, crr, cdof = torch.as_tensor(st["char_root_pos"].copy()), torch.as_tensor(st["char_root_rot"].copy()), torch.as_tensor(st["char_dof_pos"].copy())
+    with torch.no_grad():
+        tp.step_path(cm, lib, ids, times, crp, crr, cdof, 1.0 / 30.0)  # warm-up
+        t0 = time.time(); steps = 0
+        while steps < 2 or (time.time() - t0 < seconds and steps < 1000):
+            tp.step_path(cm, lib, ids, times + steps / 30.0, crp, crr, cdof, 1.0 / 30.0); steps += 1
+        dt = time.time() - t0
     return {"value": n * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} {'full (dynamics + obs/reward/done)' if dynamics_on else 'kinematic'} steps x {n} envs, C/C++ oracle "
-                      "(scalar, -O2, one thread per core), same scene and state"}
+            "sample": f"{steps} x {n} envs: PyTorch-CPU op sequence of the reference's motion_lib.calc_motion_frame (7 samples per env) + kin_char_model "
+                      "dof_to_rot / rot_to_dof / forward_kinematics (character, reference, 6 targets), torch.set_num_threads(cores); no terrain rays, "
+                      "observation assembly or reward"}
 
 
 def _profile_json(name):

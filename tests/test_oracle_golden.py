@@ -225,3 +225,39 @@ def test_recorded_isaacgym_obs(oracle, orc_char):
         d = np.abs(h - obs[i, 871:])[inb]
         tot += inb.sum(); ok += (d < 1e-5).sum()
     assert tot > 0.7 * n * 441 and ok / tot > 0.999, (tot, ok)
+
+
+def test_torch_path_vs_golden(char_golden):
+    """oracle/torch_path.py (the PyTorch-CPU op sequence bench.py times as the north star's CPU baseline) against the golden
+    vectors of the real reference."""
+    import torch
+    from oracle import torch_path as tp
+    cg = char_golden
+    cm = tp.CharModel(cg["parent"], cg["local_translation"], cg["local_rotation"], cg["joint_type"], cg["joint_axis"], cg["dof_idx"], int(cg["dof_size"]))
+    T = lambda a: torch.as_tensor(np.asarray(a))
+    k = golden("kin_ops")
+    close(cm.dof_to_rot(T(k["dof"])).numpy(), k["joint_rot"], what="dof_to_rot")
+    close(cm.rot_to_dof(T(k["joint_rot"])).numpy(), k["dof_back"], tol=5e-6, what="rot_to_dof")
+    close(cm.rot_to_dof(T(k["joint_rot_rand"])).numpy(), k["dof_rand"], tol=5e-6, what="rot_to_dof rand")
+    bp, br = cm.forward_kinematics(T(k["root_pos"]), T(k["root_rot"]), T(k["joint_rot"]))
+    close(bp.numpy(), k["body_pos"], what="fk pos"); close(br.numpy(), k["body_rot"], what="fk rot")
+    g = golden("motion_lib")
+    lib = tp.MotionLib(g)
+    ids, times = T(g["q_ids"]).long(), T(g["q_times"]).float()
+    i0, i1, bl = lib.calc_frame_blend(ids, times)
+    assert np.array_equal(i0.numpy(), g["idx0"]) and np.array_equal(i1.numpy(), g["idx1"])
+    close(bl.numpy(), g["blend"], what="blend")
+    out = lib.calc_motion_frame(ids, times)
+    for o, name in zip(out, ["root_pos", "root_rot", "root_vel", "root_ang_vel", "joint_rot", "dof_vel", "contacts"]):
+        close(o.numpy(), g[name], tol=5e-6, what=name)
+    bp, _ = cm.forward_kinematics(out[0], out[1], out[4])
+    close(bp.numpy(), g["body_pos"], tol=5e-6, what="body_pos")
+    close(cm.rot_to_dof(out[4]).numpy(), g["dof_pos"], tol=5e-6, what="dof_pos")
+    w = golden("motion_lib_wrap")  # WRAP loop offset
+    import copy
+    lib2 = tp.MotionLib({**{kk: g[kk] for kk in g.files}, "motion_loop_modes": np.ones(4, np.int64)})
+    # the wrap golden is the civilization clip alone: motion 1 of the 4-clip tables
+    o2 = lib2.calc_motion_frame(torch.ones(64, dtype=torch.long), T(w["q_times"]).float())
+    close(o2[0].numpy(), w["root_pos"], tol=5e-6, what="wrap root_pos"); close(o2[4].numpy(), w["joint_rot"], tol=5e-6, what="wrap joint_rot")
+    res = tp.step_path(cm, lib, ids[:64], times[:64].clamp(min=0.0), T(k["root_pos"][:64]), T(k["root_rot"][:64]), T(k["dof"][:64]), 1.0 / 30.0)
+    assert res[2].shape == (64 * 6, 15, 3) and all(torch.isfinite(r).all() for r in res)
