@@ -250,6 +250,10 @@ int parc_env_get_frame_vel_tables(ParcEnv *env, float *root_vel_host, float *roo
 int parc_env_profile_step(ParcEnv *env, const float *action_dev, void *stream, int32_t iters, float *avg_ms_out,
                           float *avg_post_kernel_ms_out);
 
+/* The waves of a k_dynamics_wave block hand records to each other through LDS flags; a wait is bounded so that a protocol
+ * error cannot hang the GPU.  Number of waits that ever hit the bound on this device (synchronises; must be 0; < 0 = error). */
+int parc_env_dynamics_timeouts(ParcEnv *env);
+
 /* average duration of k_dynamics in the last parc_env_profile_step call (0 when dynamics is off) */
 float parc_env_last_dynamics_ms(ParcEnv *env);
 

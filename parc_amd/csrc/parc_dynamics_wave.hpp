@@ -157,6 +157,8 @@ inline bool build_wave_tables(const DynModel &M, const CoopTables &C, WaveTables
 
 #if defined(__HIPCC__)
 
+__device__ unsigned int g_wave_timeouts; // flag waits (substep loop) that hit their bound: must stay 0, see parc_env_dynamics_timeouts
+
 // Diagnostic builds only (-DPARC_STAMPS): cycles between consecutive stamp points, summed per wave role over all blocks.
 // Even slots = work segments, odd slots = the barrier wait that follows (see the WSTAMP calls in the substep loop).
 #ifdef PARC_STAMPS
@@ -725,7 +727,10 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
     };
     auto await = [&](int f, int sub) __attribute__((always_inline)) {
         int spins = 0;
-        while (s_flag[f] <= sub && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(2); // bounded: a protocol error must not hang the GPU
+        while (s_flag[f] <= sub) { // bounded: a protocol error must not hang the GPU, and must not go unnoticed (s_flag[15], reported at the end)
+            if (++spins == (1 << 22)) { s_flag[15] = 1; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     };
     auto trunk_kinematics = [&](int sub) __attribute__((always_inline)) { // wave 0
@@ -948,6 +953,7 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
         }
         WSTAMP(9);
     }
+    if (s_flag[15] != 0 && lane == 0) atomicAdd(&g_wave_timeouts, 1u); // (a wave that is through early may miss a later timeout of another wave: the counter is a lower bound)
     // ---- write back -----------------------------------------------------------------------------------------------------
     if (!env_ok) return;
     float *odp = buf.char_dof_pos + (size_t)D_ * e, *odv = buf.char_dof_vel + (size_t)D_ * e, *ocf = buf.contact_forces + 3 * (size_t)e * B_;

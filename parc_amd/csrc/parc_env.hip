@@ -2110,6 +2110,15 @@ extern "C" int parc_env_get_frame_vel_tables(ParcEnv *e, float *root_vel, float 
     return PARC_OK;
 }
 
+extern "C" int parc_env_dynamics_timeouts(ParcEnv *e) {
+    if (!e) return fail(PARC_ERR_INVALID, "null env");
+    unsigned int v = 0;
+    HIPCHK(hipSetDevice(e->cfg.device));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(&v, HIP_SYMBOL(parcdyn::g_wave_timeouts), sizeof(v)));
+    return (int)(v > 0x7fffffffu ? 0x7fffffffu : v);
+}
+
 extern "C" float parc_env_last_dynamics_ms(ParcEnv *e) { return e ? e->last_dyn_ms : 0.f; }
 
 extern "C" const char *parc_env_dynamics_kernel(ParcEnv *e) {

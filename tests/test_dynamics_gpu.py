@@ -89,6 +89,7 @@ def test_dynamics_at_bench_sizes(tmp_path, n, motions):
     sp = to_np(env._char_root_vel.norm(dim=-1))
     assert np.quantile(sp, 0.99) < 16.0 and sp.max() < 30.0, (np.quantile(sp, 0.99), sp.max())   # nobody is launched; 16 m/s = a 12 m fall
     assert np.mean(np.abs(to_np(env._char_contact_forces)).reshape(n, -1).max(1) > 20 * mg) < 5e-3
+    assert env._lib.parc_env_dynamics_timeouts(env._handle) == 0   # no flag wait between the waves of a block ever hit its bound
 
 
 def test_wave_kernel_vs_coop_on_a_slice_of_the_cfg3_scene(tmp_path, monkeypatch):
