@@ -223,7 +223,24 @@ __device__ __forceinline__ float wave_sum(float v) { // butterfly over the 64 la
     return v;
 }
 
-template <int MODE>
+// Sum within each 16-lane row with four DPP row rotations (no LDS crossbar traffic): every lane of a row ends up with its row's total.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row_sum16(float v) {
+    v = v + dpp_f32<0x128>(v); // row_ror:8
+    v = v + dpp_f32<0x124>(v); // row_ror:4
+    v = v + dpp_f32<0x122>(v); // row_ror:2
+    v = v + dpp_f32<0x121>(v); // row_ror:1
+    return v;
+}
+__device__ __forceinline__ float lane_value(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
+// MIRROR = false: none of the optional outputs (the ref_* mirrors of the reference's tensors, ray_hfs, tracking_error) is bound --
+// the training configuration.  Their pointers and null checks then leave the kernel (20+ SGPRs: the kernel is at the SGPR limit and every
+// scalar spilled to a VGPR lane comes back as a VALU instruction).
+template <int MODE, bool MIRROR>
 __global__ __launch_bounds__(64, 4) void k_env_post(const StepParams P, const int64_t *__restrict__ env_ids,
                                                  const int *__restrict__ env_ids32, const int *__restrict__ count_dev, int count) {
     // P arrives by value in the kernarg segment: its pointers are then known to be global (global_load / global_store
@@ -231,7 +248,8 @@ __global__ __launch_bounds__(64, 4) void k_env_post(const StepParams P, const in
     extern __shared__ __align__(16) float s_obs[]; // staged observation prefix [0, off_tarc)
     __shared__ int s_tab_raw[HIER_STAGED_WORDS];
     const HierTables &s_tab = *reinterpret_cast<const HierTables *>(s_tab_raw); // only the staged members are touched through it
-    __shared__ float4 s_q[8][16];   // row r: quats 0..14 (0 = root), slot 15 = root position
+    __shared__ float4 s_q[8][16];   // row r: quats 0..14 (0 = root), slot 15 = root position.  Target rows (r >= 2) hold lr (x) q for the joints
+    __shared__ float4 s_lq[2][16];  // rows 0, 1: lr (x) q of the joints (s_q keeps their raw quaternions for the reward)
     __shared__ float4 s_fk[80];     // FK positions: rows 0,1 all bodies [r*16+b]; target rows key slots [32+(r-2)*8+k]
     __shared__ float4 s_cbp[16];    // simulator rigid-body positions of the character
     __shared__ float4 s_rpo[8];     // per target row: heading-frame root offset
@@ -385,7 +403,7 @@ __global__ __launch_bounds__(64, 4) void k_env_post(const StepParams P, const in
     // ================= height rays (mgdm_dm_util.py:128-145; terrain_util.py:146-156) =================
     {
         float *hrow = orow + P.off_hf;
-        float *hmirror = P.buf.ray_hfs ? P.buf.ray_hfs + (size_t)e * P.R : nullptr;
+        float *hmirror = MIRROR && P.buf.ray_hfs ? P.buf.ray_hfs + (size_t)e * P.R : nullptr;
         for (int base = 0; base < P.R; base += 64 * RAY_UNROLL) {
             if (base > 0) {
 #pragma unroll
@@ -449,11 +467,17 @@ __global__ __launch_bounds__(64, 4) void k_env_post(const StepParams P, const in
                     res = slerp(A, Bv, bb);
                 }
             }
-            s_q[r][i] = res;
+            if (i >= 1 && i < B) { // the FK chains multiply parent (x) (lr (x) q): the inner product is formed here, once per joint,
+                                   // instead of once per chain level (same operations, same order)
+                const Q4 lq = quat_mul(mk4(s_tab.lr[i][0], s_tab.lr[i][1], s_tab.lr[i][2], s_tab.lr[i][3]), res);
+                if (r < 2) { s_lq[r][i] = lq; s_q[r][i] = res; } else s_q[r][i] = lq;
+            } else {
+                s_q[r][i] = res;
+            }
             if (r == 1) { // optional mirrors of the reference's ref_* tensors
-                if (i == 0 && P.buf.ref_root_rot) *(float4 *)(P.buf.ref_root_rot + 4 * (size_t)e) = res;
-                if (i >= 1 && i < B && P.buf.ref_joint_rot) *(float4 *)(P.buf.ref_joint_rot + 4 * ((size_t)e * J + i - 1)) = res;
-                if (i == 15 && P.buf.ref_root_pos) {
+                if (MIRROR && i == 0 && P.buf.ref_root_rot) *(float4 *)(P.buf.ref_root_rot + 4 * (size_t)e) = res;
+                if (MIRROR && i >= 1 && i < B && P.buf.ref_joint_rot) *(float4 *)(P.buf.ref_joint_rot + 4 * ((size_t)e * J + i - 1)) = res;
+                if (MIRROR && i == 15 && P.buf.ref_root_pos) {
                     float *o = P.buf.ref_root_pos + 3 * (size_t)e;
                     o[0] = res.x; o[1] = res.y; o[2] = res.z;
                 }
@@ -485,7 +509,7 @@ __global__ __launch_bounds__(64, 4) void k_env_post(const StepParams P, const in
             if (bd < B) {
                 if (s == 0) {
                     s_refct[bd] = v[k];
-                    if (P.buf.ref_contacts) P.buf.ref_contacts[(size_t)e * B + bd] = v[k];
+                    if (MIRROR && P.buf.ref_contacts) P.buf.ref_contacts[(size_t)e * B + bd] = v[k];
                 } else {
                     orow[P.off_tarc + (s - 1) * B + bd] = v[k];
                 }
@@ -494,9 +518,9 @@ __global__ __launch_bounds__(64, 4) void k_env_post(const StepParams P, const in
     } else if (lane >= 32 && lane < 32 + nvel) {
         const int c = lane - 32;
         s_refvel[c] = cA;
-        if (c == 0 && P.buf.ref_root_vel) { float *o = P.buf.ref_root_vel + 3 * (size_t)e; o[0] = cA.x; o[1] = cA.y; o[2] = cA.z; }
-        if (c == 1 && P.buf.ref_root_ang_vel) { float *o = P.buf.ref_root_ang_vel + 3 * (size_t)e; o[0] = cA.x; o[1] = cA.y; o[2] = cA.z; }
-        if (c >= 2 && P.buf.ref_dof_vel) {
+        if (MIRROR && c == 0 && P.buf.ref_root_vel) { float *o = P.buf.ref_root_vel + 3 * (size_t)e; o[0] = cA.x; o[1] = cA.y; o[2] = cA.z; }
+        if (MIRROR && c == 1 && P.buf.ref_root_ang_vel) { float *o = P.buf.ref_root_ang_vel + 3 * (size_t)e; o[0] = cA.x; o[1] = cA.y; o[2] = cA.z; }
+        if (MIRROR && c >= 2 && P.buf.ref_dof_vel) {
             const float vv[4] = {cA.x, cA.y, cA.z, cA.w};
             for (int k = 0; k < 4; ++k) { const int d = 4 * (c - 2) + k; if (d < D) P.buf.ref_dof_vel[(size_t)e * D + d] = vv[k]; }
         }
@@ -509,11 +533,12 @@ __global__ __launch_bounds__(64, 4) void k_env_post(const StepParams P, const in
         const int k = lane >> 3, c = lane & 7;
         if (k < 2 + S) {
             Q4 prot = s_q[k][0];
+            const float4 *jq = k < 2 ? s_lq[k] : s_q[k];
             const float4 pp = s_q[k][15];
             V3 ppos = mk3(pp.x, pp.y, pp.z);
             if (c == 0 && k < 2) {
                 s_fk[k * 16] = make_float4(ppos.x, ppos.y, ppos.z, 0.f);
-                if (P.tracking) s_br[k][0] = prot;
+                if (MIRROR && P.tracking) s_br[k][0] = prot;
             }
 #pragma unroll 1
             for (int d = 0; d < PARC_MAX_FK_DEPTH; ++d) {
@@ -521,11 +546,10 @@ __global__ __launch_bounds__(64, 4) void k_env_post(const StepParams P, const in
                 if (b < 0) break;
                 const V3 wt = quat_rotate(prot, mk3(s_tab.lt[b][0], s_tab.lt[b][1], s_tab.lt[b][2]));
                 ppos = mk3(ppos.x + wt.x, ppos.y + wt.y, ppos.z + wt.z);
-                const Q4 lr = mk4(s_tab.lr[b][0], s_tab.lr[b][1], s_tab.lr[b][2], s_tab.lr[b][3]);
-                prot = quat_mul(prot, quat_mul(lr, s_q[k][b]));
+                prot = quat_mul(prot, jq[b]);
                 if (k < 2) {
                     s_fk[k * 16 + b] = make_float4(ppos.x, ppos.y, ppos.z, 0.f);
-                    if (P.tracking) s_br[k][b] = prot;
+                    if (MIRROR && P.tracking) s_br[k][b] = prot;
                 } else {
                     const int slot = s_tab.key_slot[b];
                     if (slot >= 0) s_fk[32 + (k - 2) * 8 + slot] = make_float4(ppos.x, ppos.y, ppos.z, 0.f);
@@ -559,15 +583,18 @@ __global__ __launch_bounds__(64, 4) void k_env_post(const StepParams P, const in
 
     if (MODE == MODE_STEP) {
         __syncthreads(); // s_cbp
-        // ---- reward terms, one per lane (mgdm_dm_util.py:270-333, 498-518), reduced with wave butterflies ----
-        float t_pose = 0.f, t_vel = 0.f, t_key = 0.f, t_con = 0.f;
-        if (lane < J) { // pose: angle of ref (x) conj(char) per joint
-            const float d = quat_diff_angle(s_q[0][1 + lane], s_q[1][1 + lane]);
-            t_pose = T->joint_err_w[lane] * d * d;
+        // ---- reward terms, one per lane (mgdm_dm_util.py:270-333, 498-518).  Row layout of the two partial-sum registers:
+        //   va: row 0 = joint pose terms (lane J of row 0 carries the root rotation angle, not summed), row 2 = contact terms,
+        //       row 3 = key-body terms;  vb: rows 0..1 = dof velocity terms (and beyond, for D > 32).
+        float va = 0.f, vb = 0.f, dang = 0.f;
+        if (lane <= J) { // angle of ref (x) conj(char): joints on lanes < J, the root on lane J (slot 0 of both rows)
+            const int slot = lane < J ? 1 + lane : 0;
+            dang = quat_diff_angle(s_q[0][slot], s_q[1][slot]);
+            if (lane < J) va = T->joint_err_w[lane] * dang * dang;
         }
         if (lane < D) {
             const float v = ((const float *)s_refvel)[8 + lane] - s_cdofv[lane];
-            t_vel = T->dof_err_w[lane] * v * v;
+            vb = T->dof_err_w[lane] * v * v;
         }
         if (lane >= 48 && lane < 48 + K) { // key positions: simulator bodies vs reference FK (ig_parkour_env.py:987)
             const int b = s_tab.key_ids[lane - 48];
@@ -575,14 +602,14 @@ __global__ __launch_bounds__(64, 4) void k_env_post(const StepParams P, const in
             const float dx = (tk.x - trp.x) - (kp.x - root_pos.x);
             const float dy = (tk.y - trp.y) - (kp.y - root_pos.y);
             const float dz = (tk.z - trp.z) - (kp.z - root_pos.z);
-            t_key = dx * dx + dy * dy + dz * dz;
+            va = dx * dx + dy * dy + dz * dz;
         }
         if (lane >= 32 && lane < 32 + B) { // contact term
             const int b = lane - 32;
             const float tar = s_refct[b], f = s_cfn[b];
             float cr = -(1.0f - tar) * f;
             cr = cr + tar * f;
-            t_con = T->contact_w[b] * cr;
+            va = T->contact_w[b] * cr;
         }
         // ---- early termination (mgdm_dm_util.py:335-402) ----
         bool bad = false;
@@ -595,29 +622,33 @@ __global__ __launch_bounds__(64, 4) void k_env_post(const StepParams P, const in
             bad = (dx * dx + dy * dy + dz * dz) > lim * lim;
         }
         const bool pose_fail_any = __ballot(bad) != 0ull;
-        const float pose_err = wave_sum(t_pose), vel_err = wave_sum(t_vel), key_err = wave_sum(t_key), csum = wave_sum(t_con);
+        const float root_rot_angle = lane_value(dang, J);
+        va = row_sum16(va); vb = row_sum16(vb);
+        const float pose_err = lane_value(va, 0), csum = lane_value(va, 32), key_err = lane_value(va, 48);
+        const float vel_err = (lane_value(vb, 0) + lane_value(vb, 16)) + (lane_value(vb, 32) + lane_value(vb, 48));
 
-        // uniform tail: every lane computes the same scalars (no divergence), lane 0 stores
+        // scalar tail: the five exponentials run on five lanes, everything else is uniform; lane 0 stores
         const float4 trp = s_q[1][15];
-        const Q4 trr = s_q[1][0];
         float rdx = trp.x - root_pos.x, rdy = trp.y - root_pos.y, rdz = trp.z - root_pos.z;
         if (!P.track_root) { rdx = 0.f; rdy = 0.f; }
         if (!P.track_root_h) rdz = 0.f;
         const float root_pos_err = rdx * rdx + rdy * rdy + rdz * rdz;
         const float4 tv = s_refvel[0], tav = s_refvel[1];
-        const float rvx = __shfl(aux0, 30, 64), rvy = __shfl(aux1, 30, 64), rvz = __shfl(aux2, 30, 64);
-        const float rax = __shfl(aux0, 31, 64), ray_ = __shfl(aux1, 31, 64), raz = __shfl(aux2, 31, 64);
-        const float root_rot_angle = quat_diff_angle(root_rot, trr);
+        const float rvx = lane_value(aux0, 30), rvy = lane_value(aux1, 30), rvz = lane_value(aux2, 30);
+        const float rax = lane_value(aux0, 31), ray_ = lane_value(aux1, 31), raz = lane_value(aux2, 31);
         const float rre = root_rot_angle * root_rot_angle;
         float d0 = tv.x - rvx, d1 = tv.y - rvy, d2 = tv.z - rvz;
         const float rve = d0 * d0 + d1 * d1 + d2 * d2;
         d0 = tav.x - rax; d1 = tav.y - ray_; d2 = tav.z - raz;
         const float rave = d0 * d0 + d1 * d1 + d2 * d2;
-        const float pose_r = expf(-0.25f * pose_err);
-        const float vel_r = expf(-0.01f * vel_err);
-        const float root_pose_r = expf(-5.0f * (root_pos_err + 0.1f * rre));
-        const float root_vel_r = expf(-1.0f * (rve + 0.1f * rave));
-        const float key_pos_r = expf(-10.0f * key_err);
+        float earg = -0.25f * pose_err;
+        earg = lane == 1 ? -0.01f * vel_err : earg;
+        earg = lane == 2 ? -5.0f * (root_pos_err + 0.1f * rre) : earg;
+        earg = lane == 3 ? -1.0f * (rve + 0.1f * rave) : earg;
+        earg = lane == 4 ? -10.0f * key_err : earg;
+        const float eval = expf(earg);
+        const float pose_r = lane_value(eval, 0), vel_r = lane_value(eval, 1), root_pose_r = lane_value(eval, 2),
+                    root_vel_r = lane_value(eval, 3), key_pos_r = lane_value(eval, 4);
         float rew = P.pose_w * pose_r + P.vel_w * vel_r + P.root_pos_w * root_pose_r + P.root_vel_w * root_vel_r + P.key_pos_w * key_pos_r;
         const float contact_pen = csum / (float)B; // torch.mean over bodies (ig_parkour_env.py:1033)
         rew = rew + contact_pen;
@@ -660,19 +691,19 @@ __global__ __launch_bounds__(64, 4) void k_env_post(const StepParams P, const in
         }
 
         // optional outputs: ref body positions / dof positions, tracking error
-        if (P.buf.ref_body_pos && lane < B) {
+        if (MIRROR && P.buf.ref_body_pos && lane < B) {
             float *o = P.buf.ref_body_pos + 3 * ((size_t)e * B + lane);
             const float4 v = s_fk[16 + lane];
             o[0] = v.x; o[1] = v.y; o[2] = v.z;
         }
-        if (P.buf.ref_dof_pos && lane >= 1 && lane < B) { // kin_char_model.py:601
+        if (MIRROR && P.buf.ref_dof_pos && lane >= 1 && lane < B) { // kin_char_model.py:601
             const int ty = T->h.jtype[lane];
             float out3[3] = {0.f, 0.f, 0.f};
             joint_rot_to_dof(ty, T->h.axis[lane], s_q[1][lane], out3);
             const int nd = ty == PARC_JOINT_HINGE ? 1 : (ty == PARC_JOINT_SPHERICAL ? 3 : 0);
             for (int k = 0; k < nd; ++k) P.buf.ref_dof_pos[(size_t)e * D + T->h.dof_idx[lane] + k] = out3[k];
         }
-        if (P.tracking && P.buf.tracking_error) { // mgdm_dm_util.py:521-553
+        if (MIRROR && P.tracking && P.buf.tracking_error) { // mgdm_dm_util.py:521-553
             float e_rot = 0.f, e_pos = 0.f, e_dv = 0.f;
             if (lane < B) {
                 e_rot = fabsf(quat_diff_angle(s_br[0][lane], s_br[1][lane]));
@@ -1663,8 +1694,17 @@ static int launch_post(ParcEnv *e, int mode, const int64_t *ids, int count, hipS
     if (count <= 0) return PARC_OK;
     const int grid = count;
     if (!prep_done) hipLaunchKernelGGL(k_env_prep, dim3((count + 3) / 4), dim3(64), 0, st, e->sp, ids, ids32, count_dev, count);
-    if (mode == MODE_STEP) hipLaunchKernelGGL(k_env_post<MODE_STEP>, dim3(grid), dim3(64), e->lds_bytes, st, e->sp, ids, ids32, count_dev, count);
-    else hipLaunchKernelGGL(k_env_post<MODE_OBS>, dim3(grid), dim3(64), e->lds_bytes, st, e->sp, ids, ids32, count_dev, count);
+    const ParcEnvBuffers &b = e->sp.buf;
+    const bool mirror = b.ref_root_pos || b.ref_root_rot || b.ref_root_vel || b.ref_root_ang_vel || b.ref_joint_rot || b.ref_dof_pos || b.ref_dof_vel ||
+                        b.ref_body_pos || b.ref_contacts || b.ray_hfs || b.tracking_error;
+    if (mode == MODE_STEP) {
+        if (mirror) hipLaunchKernelGGL((k_env_post<MODE_STEP, true>), dim3(grid), dim3(64), e->lds_bytes, st, e->sp, ids, ids32, count_dev, count);
+        else hipLaunchKernelGGL((k_env_post<MODE_STEP, false>), dim3(grid), dim3(64), e->lds_bytes, st, e->sp, ids, ids32, count_dev, count);
+    } else {
+        if (mirror) hipLaunchKernelGGL((k_env_post<MODE_OBS, true>), dim3(grid), dim3(64), e->lds_bytes, st, e->sp, ids, ids32, count_dev, count);
+        else hipLaunchKernelGGL((k_env_post<MODE_OBS, false>), dim3(grid), dim3(64), e->lds_bytes, st, e->sp, ids, ids32, count_dev, count);
+    }
+
     HIPCHK(hipGetLastError());
     return PARC_OK;
 }
