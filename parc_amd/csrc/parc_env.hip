@@ -401,6 +401,8 @@ __global__ __launch_bounds__(64, 4) void k_env_post(const StepParams P, const in
     STAMP(1);
 
     // ================= height rays (mgdm_dm_util.py:128-145; terrain_util.py:146-156) =================
+    // Two loops, one per source of the heights, so that the common one reads the LDS tile with plain ds_read (a pointer that may
+    // be LDS or global becomes a flat load, whose wait also covers the stores of the previous ray).
     {
         float *hrow = orow + P.off_hf;
         float *hmirror = MIRROR && P.buf.ray_hfs ? P.buf.ray_hfs + (size_t)e * P.R : nullptr;
@@ -409,25 +411,50 @@ __global__ __launch_bounds__(64, 4) void k_env_post(const StepParams P, const in
 #pragma unroll
                 for (int i = 0; i < RAY_UNROLL; ++i) { const int r = base + lane + 64 * i; rayp[i] = r < P.R ? ((const float2 *)P.ray_points)[r] : make_float2(0.f, 0.f); }
             }
+            if (tr >= 0) { // the tile radius covers the whole fan by construction (parc_env_load_terrain): clamp, no fallback
+                // every tile index is formed before the first store: a later use of a loaded ray point would have to wait for
+                // the stores issued in between (one counter orders loads and stores).  Lanes past the end of the fan carry the
+                // point (0, 0), a valid cell; only their stores are masked.
+                int tix[RAY_UNROLL];
 #pragma unroll
-            for (int i = 0; i < RAY_UNROLL; ++i) {
-                const int r = base + lane + 64 * i;
-                if (r < P.R) {
-                    const float px = (rayp[i].x * ch - rayp[i].y * sh) + gx; // rotate_2d_vec torch_util.py:651
-                    const float py = (rayp[i].x * sh + rayp[i].y * ch) + gy;
-                    const int ix = cell_index_rcp(px, P.min_x, P.dx, P.rdx), iy = cell_index_rcp(py, P.min_y, P.dy, P.rdy);
-                    float h;
-                    if (tr >= 0) { // the tile radius covers the whole fan by construction (parc_env_load_terrain): clamp, no fallback
+                for (int i = 0; i < RAY_UNROLL; ++i) {
+                    tix[i] = 0;
+                    if (base + 64 * i < P.R) { // uniform
+                        const float px = (rayp[i].x * ch - rayp[i].y * sh) + gx; // rotate_2d_vec torch_util.py:651
+                        const float py = (rayp[i].x * sh + rayp[i].y * ch) + gy;
+                        const int ix = cell_index_rcp(px, P.min_x, P.dx, P.rdx), iy = cell_index_rcp(py, P.min_y, P.dy, P.rdy);
                         const int a = min(max(ix - ox, 0), TW - 1), bq = min(max(iy - oy, 0), TW - 1);
-                        h = s_tile[a * TW + bq];
-                    } else { // fan too wide for the LDS tile: direct gathers
-                        const int cx = min(max(ix, 0), P.X - 1), cy = min(max(iy, 0), P.Y - 1);
-                        h = P.hf[(size_t)cx * P.Y + cy];
+                        tix[i] = a * TW + bq;
                     }
-                    h = h - gz;
-                    h = fminf(fmaxf(h, P.min_obs_h), P.max_obs_h);
-                    hrow[r] = h; // 256 contiguous bytes per wave store: no staging needed
-                    if (hmirror) hmirror[r] = h;
+                    asm volatile("" : "+v"(tix[i])); // keep the index arithmetic here (not sunk below the stores)
+                }
+                float hv[RAY_UNROLL];
+#pragma unroll
+                for (int i = 0; i < RAY_UNROLL; ++i) hv[i] = s_tile[tix[i]]; // one batch of LDS reads, one wait
+#pragma unroll
+                for (int i = 0; i < RAY_UNROLL; ++i) {
+                    const int r = base + lane + 64 * i;
+                    if (r < P.R) {
+                        float h = hv[i] - gz;
+                        h = fminf(fmaxf(h, P.min_obs_h), P.max_obs_h);
+                        hrow[r] = h; // 256 contiguous bytes per wave store: no staging needed
+                        if (hmirror) hmirror[r] = h;
+                    }
+                }
+            } else { // fan too wide for the LDS tile: direct gathers
+#pragma unroll
+                for (int i = 0; i < RAY_UNROLL; ++i) {
+                    const int r = base + lane + 64 * i;
+                    if (r < P.R) {
+                        const float px = (rayp[i].x * ch - rayp[i].y * sh) + gx;
+                        const float py = (rayp[i].x * sh + rayp[i].y * ch) + gy;
+                        const int ix = cell_index_rcp(px, P.min_x, P.dx, P.rdx), iy = cell_index_rcp(py, P.min_y, P.dy, P.rdy);
+                        const int cx = min(max(ix, 0), P.X - 1), cy = min(max(iy, 0), P.Y - 1);
+                        float h = P.hf[(size_t)cx * P.Y + cy] - gz;
+                        h = fminf(fmaxf(h, P.min_obs_h), P.max_obs_h);
+                        hrow[r] = h;
+                        if (hmirror) hmirror[r] = h;
+                    }
                 }
             }
         }
