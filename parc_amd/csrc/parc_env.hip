@@ -829,21 +829,21 @@ __global__ __launch_bounds__(1024) void k_done_scatter(const unsigned char *__re
     }
 }
 
-// One 256-thread block per motion.  The block sweeps the env-ordered list and compacts (stable, by rank) the
-// FAIL flags of its motion's entries into an LDS bit string; thread 0 then applies the chain in that order:
-// f <- f*(1-w) + (FAIL ? w : 0)  (adding +0.0f leaves f*(1-w) unchanged, so this is the reference's two-branch
-// update, dm_env.py:651-658, bit for bit).
-#define EMA_CAP_BITS 65536
+// One 1024-thread block per motion.  The block sweeps the env-ordered list and compacts (stable, by rank) the addends of its
+// motion's entries -- w for FAIL, +0 otherwise -- into LDS; thread 0 then applies the chain in that order:
+// f <- f*(1-w) + addend  (adding +0.0f leaves f*(1-w) unchanged, so this is the reference's two-branch update,
+// dm_env.py:651-658, bit for bit).  The chain is inherently serial (each update rounds): only its two dependent VALU
+// operations per entry stay on it, the addends arrive four at a time from LDS.
+#define EMA_CAP 8192
 __global__ __launch_bounds__(1024) void k_fail_rate_ema(const int *__restrict__ done_key, const int *__restrict__ reset_count,
                                                        float *fail_rates, int M, float w) {
-    __shared__ unsigned s_bits[EMA_CAP_BITS / 32];
+    __shared__ __align__(16) float s_add[EMA_CAP];
     __shared__ int s_wtot[16];
     __shared__ float s_f;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = blockIdx.x;
     const int k = *reset_count;
     if (k == 0 || m >= M) return;
     const float keep = (float)(1.0 - (double)w);
-    for (int i = tid; i < EMA_CAP_BITS / 32; i += 1024) s_bits[i] = 0u;
     if (tid == 0) s_f = fail_rates[m];
     __syncthreads();
     int nmatch = 0;
@@ -857,39 +857,38 @@ __global__ __launch_bounds__(1024) void k_fail_rate_ema(const int *__restrict__ 
         __syncthreads();
         int woff = 0, total = 0;
         for (int q = 0; q < 16; ++q) { const int c = s_wtot[q]; if (q < wv) woff += c; total += c; }
-        if (match && (v & 1)) {
-            const int pos = nmatch + woff + __popcll(mask & ((1ull << lane) - 1ull));
-            atomicOr(&s_bits[pos >> 5], 1u << (pos & 31));
-        }
+        if (match) s_add[nmatch + woff + __popcll(mask & ((1ull << lane) - 1ull))] = (v & 1) ? w : 0.0f;
         nmatch += total;
         any = any || total > 0;
         __syncthreads();
         const bool last = tile + 1024 >= k;
-        if (nmatch + 1024 > EMA_CAP_BITS || (last && nmatch > 0)) { // flush: sequential chain over the buffered flags
+        if (nmatch + 1024 > EMA_CAP || (last && nmatch > 0)) { // flush: sequential chain over the buffered addends
             if (tid == 0) {
-                // the chain is inherently serial (each update rounds): keep only the two dependent VALU ops per entry on
-                // it -- flag words are fetched 4 at a time, addends are formed off the chain
                 float f = s_f;
-                const int nw = (nmatch + 31) >> 5;
-                for (int wi = 0; wi < nw; wi += 4) {
-                    unsigned bw[4];
+                int i4 = 0;
+                const float4 *a4 = (const float4 *)s_add;
+                for (; i4 + 32 <= nmatch; i4 += 32) { // eight LDS reads in flight: only the first one's latency is exposed
+                    float4 q[8];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) bw[q] = wi + q < nw ? s_bits[wi + q] : 0u;
+                    for (int j = 0; j < 8; ++j) q[j] = a4[(i4 >> 2) + j];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int cnt = min(32, nmatch - ((wi + q) << 5));
-                        if (cnt == 32) {
-#pragma unroll
-                            for (int j = 0; j < 32; ++j) { f = f * keep; f = f + (((bw[q] >> j) & 1u) ? w : 0.0f); }
-                        } else {
-                            for (int j = 0; j < cnt; ++j) { f = f * keep; f = f + (((bw[q] >> j) & 1u) ? w : 0.0f); }
-                        }
+                    for (int j = 0; j < 8; ++j) {
+                        f = f * keep; f = f + q[j].x;
+                        f = f * keep; f = f + q[j].y;
+                        f = f * keep; f = f + q[j].z;
+                        f = f * keep; f = f + q[j].w;
                     }
                 }
+                for (; i4 + 4 <= nmatch; i4 += 4) {
+                    const float4 a = a4[i4 >> 2];
+                    f = f * keep; f = f + a.x;
+                    f = f * keep; f = f + a.y;
+                    f = f * keep; f = f + a.z;
+                    f = f * keep; f = f + a.w;
+                }
+                for (; i4 < nmatch; ++i4) { f = f * keep; f = f + s_add[i4]; }
                 s_f = f;
             }
-            __syncthreads();
-            if (!last) for (int q = tid; q < EMA_CAP_BITS / 32; q += 1024) s_bits[q] = 0u;
             nmatch = 0;
             __syncthreads();
         }
@@ -1095,7 +1094,9 @@ struct ResetParams {
 // arithmetic per quantity as the one-thread-per-env form it replaces (motion_frame_thread, joint_rot_to_dof, fk_thread),
 // so results are unchanged; the per-env serial chain (15 slerps + 14 exp maps + 15-body FK, ~7k instructions) becomes ~600.
 __global__ __launch_bounds__(64) void k_reset_with(const ResetParams P, const int64_t *env_ids, const int *env_ids32, const int *count_dev, int k,
-                                                   const int *motion_ids, const int *terrain_ids, const float *t0, const float *xy_noise) {
+                                                   const int *motion_ids, const int *terrain_ids, const float *t0, const float *xy_noise,
+                                                   unsigned long long *bump_calls) {
+    if (bump_calls && blockIdx.x == 0 && threadIdx.x == 0) *bump_calls += 1ull; // this launch consumed the draws of call index *bump_calls + 1
     __shared__ float4 s_q[4][16];     // [g][0] root rotation, [g][j] joint j (j >= 1)
     __shared__ float4 s_pos[4][16];   // FK: body positions
     __shared__ float4 s_rot[4][16];   // FK: body rotations
@@ -1253,10 +1254,8 @@ __device__ __forceinline__ double shfl_up_f64(double v, int d) {
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
-__global__ __launch_bounds__(1024) void k_build_cdf(const float *fail_rates, const float *motion_weights, float min_w, int M, float *cdf,
-                                                    unsigned long long *reset_calls) {
-    if (threadIdx.x == 0) *reset_calls += 1ull; // index of this reset call for the Philox stream (device-side, so that a
-                                                // captured graph replays with a fresh index every time)
+// Libraries of more than 64 motions; smaller ones are scanned by k_reset_sample itself (one launch less on the reset path).
+__global__ __launch_bounds__(1024) void k_build_cdf(const float *fail_rates, const float *motion_weights, float min_w, int M, float *cdf) {
     // rows of 1024 consecutive motions (coalesced); inside a row: wave scans through shuffles, the 16 wave totals through LDS;
     // the running total carries from row to row.  Sums are formed in double, the stored value is its fp32 rounding.
     __shared__ double s_wave[16];
@@ -1291,14 +1290,32 @@ __global__ __launch_bounds__(1024) void k_build_cdf(const float *fail_rates, con
     }
 }
 
-__global__ void k_reset_sample(const int64_t *env_ids, const int *env_ids32, const int *count_dev, int k, int M, int T, const float *cdf, const MotionMeta *meta,
-                               unsigned long long seed, const unsigned long long *call_dev, int rand_reset, int demo_mode, float noise_scale,
-                               const float *start_frac, int *motion_ids, int *terrain_ids, float *t0, float *xy_noise) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// The Philox call index of a sampling reset is *call_dev + 1; the k_reset_with launch that follows bumps the device-side counter (so
+// that a captured graph replays with a fresh index every time).
+#define CDF_LOCAL_MAX 64
+__global__ __launch_bounds__(128) void k_reset_sample(const int64_t *env_ids, const int *env_ids32, const int *count_dev, int k, int M, int T, const float *cdf_global,
+                                                      const float *fail_rates, const float *motion_weights, float min_w, const MotionMeta *meta,
+                                                      unsigned long long seed, const unsigned long long *call_dev, int rand_reset, int demo_mode, float noise_scale,
+                                                      const float *start_frac, int *motion_ids, int *terrain_ids, float *t0, float *xy_noise) {
+    __shared__ float s_cdf[CDF_LOCAL_MAX];
+    const float *cdf = cdf_global;
     if (count_dev) k = *count_dev;
+    if ((int)(blockIdx.x * blockDim.x) >= k) return; // uniform
+    if (M <= CDF_LOCAL_MAX) { // the wave scan of k_build_cdf for a library that fits one wave: same operations, same result
+        if (threadIdx.x < 64) {
+            const int lane = threadIdx.x;
+            double v = lane < M ? (double)(fmaxf(fail_rates[lane], min_w) * motion_weights[lane]) : 0.0;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const double u = shfl_up_f64(v, d); if (lane >= d) v += u; }
+            if (lane < M) s_cdf[lane] = (float)(0.0 + v);
+        }
+        __syncthreads();
+        cdf = s_cdf;
+    }
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= k) return;
     const int e = env_ids ? (int)env_ids[i] : (env_ids32 ? env_ids32[i] : i);
-    const unsigned long long call = *call_dev;
+    const unsigned long long call = *call_dev + 1ull;
     float u[4], v[4];
     philox4(seed, call, (unsigned)e * 2u, u);
     philox4(seed, call, (unsigned)e * 2u + 1u, v);
@@ -1332,6 +1349,7 @@ struct ParcEnv {
     int obs_dim;
     int64_t F = 0;
     bool bound = false, have_motions = false, have_terrain = false;
+    bool done_list_fresh = false;     // a step has produced a done list that parc_env_reset_done has not consumed yet
     StepParams sp;
     float4 *d_prep = nullptr;
     float *d_root_shadow = nullptr;   // [N][6]: root position the dynamics last wrote + what that write rounded away (k_dynamics_wave)
@@ -1702,6 +1720,7 @@ static int launch_dynamics(ParcEnv *e, const float *action_dev, hipStream_t st) 
 }
 
 static int launch_curriculum(ParcEnv *e, hipStream_t st) {
+    e->done_list_fresh = true;
     hipLaunchKernelGGL(k_done_scatter, dim3(e->nchunks), dim3(1024), 0, st, e->d_ema, e->sp.buf.motion_ids, e->N, e->d_done_list,
                        e->d_done_key, e->d_reset_count, e->sp.never_done);
     if (e->M <= 64 && !e->force_ema_leader) {
@@ -1931,8 +1950,8 @@ static ResetParams make_reset_params(ParcEnv *e) {
     return rp;
 }
 
-extern "C" int parc_env_reset_with(ParcEnv *e, const int64_t *ids, int32_t k, const int32_t *mids, const int32_t *tids, const float *t0,
-                                   const float *noise, void *stream) {
+static int reset_with_impl(ParcEnv *e, const int64_t *ids, int32_t k, const int32_t *mids, const int32_t *tids, const float *t0,
+                           const float *noise, void *stream, unsigned long long *bump_calls) {
     int rc = check_ready(e);
     if (rc) return rc;
     if (k == 0) return PARC_OK;
@@ -1941,9 +1960,24 @@ extern "C" int parc_env_reset_with(ParcEnv *e, const int64_t *ids, int32_t k, co
     const int n = k < 0 ? e->N : k;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_reset_with, dim3((n + 3) / 4), dim3(64), 0, st, make_reset_params(e), k < 0 ? nullptr : ids, (const int *)nullptr,
-                       (const int *)nullptr, n, mids, tids, t0, noise);
+                       (const int *)nullptr, n, mids, tids, t0, noise, bump_calls);
     HIPCHK(hipGetLastError());
     return launch_post(e, MODE_OBS, k < 0 ? nullptr : ids, n, st, nullptr, nullptr, /*prep_done=*/true);
+}
+
+extern "C" int parc_env_reset_with(ParcEnv *e, const int64_t *ids, int32_t k, const int32_t *mids, const int32_t *tids, const float *t0,
+                                   const float *noise, void *stream) {
+    return reset_with_impl(e, ids, k, mids, tids, t0, noise, stream, nullptr); // the caller drew the samples: the sampling counter stays
+}
+
+// motion / terrain / start time / xy noise of the envs to reset (dm_env.py:470-504): libraries of up to CDF_LOCAL_MAX motions are
+// scanned inside k_reset_sample, larger ones by k_build_cdf first
+static void launch_sample(ParcEnv *e, const int64_t *ids, const int *ids32, const int *count_dev, int n, hipStream_t st) {
+    if (e->M > CDF_LOCAL_MAX)
+        hipLaunchKernelGGL(k_build_cdf, dim3(1), dim3(1024), 0, st, e->d_fail, e->d_weights, e->cfg.min_motion_weight, e->M, e->d_cdf);
+    hipLaunchKernelGGL(k_reset_sample, dim3((n + 127) / 128), dim3(128), 0, st, ids, ids32, count_dev, n, e->M, e->T, e->d_cdf, e->d_fail, e->d_weights,
+                       e->cfg.min_motion_weight, e->d_meta, (unsigned long long)e->cfg.seed, (const unsigned long long *)e->d_reset_calls, e->cfg.rand_reset,
+                       e->cfg.demo_mode, e->cfg.rand_root_pos_offset_scale, e->d_start_frac, e->d_tmp_mid, e->d_tmp_tid, e->d_tmp_t0, e->d_tmp_noise);
 }
 
 extern "C" int parc_env_reset(ParcEnv *e, const int64_t *ids, int32_t k, void *stream) {
@@ -1953,33 +1987,26 @@ extern "C" int parc_env_reset(ParcEnv *e, const int64_t *ids, int32_t k, void *s
     if (k > e->N) return fail(PARC_ERR_INVALID, "k > num_envs");
     if (k > 0 && !ids) return fail(PARC_ERR_INVALID, "env_ids is NULL");
     const int n = k < 0 ? e->N : k;
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_build_cdf, dim3(1), dim3(1024), 0, st, e->d_fail, e->d_weights, e->cfg.min_motion_weight, e->M, e->d_cdf, e->d_reset_calls);
-    hipLaunchKernelGGL(k_reset_sample, dim3((n + 127) / 128), dim3(128), 0, st, k < 0 ? nullptr : ids, (const int *)nullptr, (const int *)nullptr, n, e->M, e->T, e->d_cdf, e->d_meta,
-                       (unsigned long long)e->cfg.seed, (const unsigned long long *)e->d_reset_calls, e->cfg.rand_reset, e->cfg.demo_mode,
-                       e->cfg.rand_root_pos_offset_scale, e->d_start_frac, e->d_tmp_mid, e->d_tmp_tid, e->d_tmp_t0, e->d_tmp_noise);
+    launch_sample(e, k < 0 ? nullptr : ids, nullptr, nullptr, n, (hipStream_t)stream);
     HIPCHK(hipGetLastError());
-    return parc_env_reset_with(e, k < 0 ? nullptr : ids, k, e->d_tmp_mid, e->d_tmp_tid, e->d_tmp_t0, e->d_tmp_noise, stream);
+    return reset_with_impl(e, k < 0 ? nullptr : ids, k, e->d_tmp_mid, e->d_tmp_tid, e->d_tmp_t0, e->d_tmp_noise, stream, e->d_reset_calls);
 }
 
 // Reset every env whose done flag was raised by the last step (base_agent.py:366-370) without the
 // nonzero()/host round trip: the step kernel's compacted done list and its device-side count drive the launch.
+// The list is consumed by the call: a second call before the next step resets nobody.
 extern "C" int parc_env_reset_done(ParcEnv *e, void *stream) {
     int rc = check_ready(e);
     if (rc) return rc;
+    if (!e->done_list_fresh) return PARC_OK;
+    e->done_list_fresh = false;
     hipStream_t st = (hipStream_t)stream;
     const int n = e->N;
-    hipLaunchKernelGGL(k_build_cdf, dim3(1), dim3(1024), 0, st, e->d_fail, e->d_weights, e->cfg.min_motion_weight, e->M, e->d_cdf, e->d_reset_calls);
-    hipLaunchKernelGGL(k_reset_sample, dim3((n + 127) / 128), dim3(128), 0, st, (const int64_t *)nullptr, e->d_done_list, e->d_reset_count + 1, n, e->M,
-                       e->T, e->d_cdf, e->d_meta, (unsigned long long)e->cfg.seed, (const unsigned long long *)e->d_reset_calls, e->cfg.rand_reset, e->cfg.demo_mode,
-                       e->cfg.rand_root_pos_offset_scale, e->d_start_frac, e->d_tmp_mid, e->d_tmp_tid, e->d_tmp_t0, e->d_tmp_noise);
+    launch_sample(e, nullptr, e->d_done_list, e->d_reset_count + 1, n, st);
     hipLaunchKernelGGL(k_reset_with, dim3((n + 3) / 4), dim3(64), 0, st, make_reset_params(e), (const int64_t *)nullptr, e->d_done_list,
-                       e->d_reset_count + 1, n, e->d_tmp_mid, e->d_tmp_tid, e->d_tmp_t0, e->d_tmp_noise);
+                       e->d_reset_count + 1, n, e->d_tmp_mid, e->d_tmp_tid, e->d_tmp_t0, e->d_tmp_noise, e->d_reset_calls);
     HIPCHK(hipGetLastError());
-    rc = launch_post(e, MODE_OBS, nullptr, n, st, e->d_done_list, e->d_reset_count + 1, /*prep_done=*/true);
-    if (rc) return rc;
-    HIPCHK(hipMemsetAsync(e->d_reset_count + 1, 0, sizeof(int), st)); // the list is consumed: a second call before the next step resets nobody
-    return PARC_OK;
+    return launch_post(e, MODE_OBS, nullptr, n, st, e->d_done_list, e->d_reset_count + 1, /*prep_done=*/true);
 }
 
 // ---- whole control step as one hipGraph launch ----------------------------------------------------------------------
@@ -2020,6 +2047,7 @@ extern "C" int parc_env_step_reset_graph(ParcEnv *e, void *stream) {
         e->graph_dirty = false;
     }
     HIPCHK(hipGraphLaunch(e->graph_exec, (hipStream_t)stream));
+    e->done_list_fresh = false; // the graph holds step + reset_done
     return PARC_OK;
 }
 
