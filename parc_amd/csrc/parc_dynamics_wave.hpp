@@ -587,20 +587,30 @@ __device__ __forceinline__ void wv_integrate_joint(const DynModel &M, const Wave
     }
 }
 
-__device__ __forceinline__ void wv_store_joint(const DynModel &M, const WaveTables &W, int b, const WvBody &B, float *dp, float *dv, float *cf) {
+// pr (optional): the env's prep record for the observation kernel (k_env_prep's output, parc_env.hip): slot b = dof -> quat of joint b
+// as the reference's kinematic model forms it FROM THE STORED DOFS (kin_char_model.py:586, torch_util.py:70-91, :337) -- the same
+// device functions on the same fp32 inputs as k_env_prep, so the record is bit-identical and that launch is not needed after a step.
+__device__ __forceinline__ void wv_store_joint(const DynModel &M, const WaveTables &W, int b, const WvBody &B, float *dp, float *dv, float *cf, float4 *pr) {
     const int jt = W.c[b].jtype, di = W.c[b].dof_idx;
     // plain copies first: selecting between struct fields inside the branches would keep the body in scratch
     const q4 jq = B.jq; const float hang = B.hang; const v3 qd = B.qd, fc = B.fcon;
     if (jt == DJ_SPHERICAL) {
         const v3 ex = qlog(jq);
         dp[di] = ex.x; dp[di + 1] = ex.y; dp[di + 2] = ex.z; dv[di] = qd.x; dv[di + 1] = qd.y; dv[di + 2] = qd.z;
-    } else if (jt == DJ_HINGE) { dp[di] = hang; dv[di] = qd.x; }
+        if (pr) pr[b] = parc::exp_map_to_quat(parc::mk3(ex.x, ex.y, ex.z));
+    } else if (jt == DJ_HINGE) {
+        dp[di] = hang; dv[di] = qd.x;
+        if (pr) pr[b] = parc::axis_angle_to_quat(parc::mk3(W.c[b].axis[0], W.c[b].axis[1], W.c[b].axis[2]), hang);
+    } else if (pr && b != 0) { // fixed joint (slot 0, the root body's, holds the heading terms)
+        pr[b] = make_float4(0.f, 0.f, 0.f, 1.f);
+    }
     cf[3 * b] = fc.x; cf[3 * b + 1] = fc.y; cf[3 * b + 2] = fc.z;
 }
 
 __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__restrict__ Mp, const WaveTables *__restrict__ Wp, DynTerrain T,
                                                           ParcEnvBuffers buf, const float *__restrict__ action,
-                                                          const float *__restrict__ env_off_all, float *__restrict__ root_shadow, int N) {
+                                                          const float *__restrict__ env_off_all, float *__restrict__ root_shadow,
+                                                          float4 *__restrict__ prep, int N) {
     extern __shared__ float smem[];
     const DynModel &M = *Mp;
     const WaveTables &W = *Wp;
@@ -957,6 +967,7 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
     // ---- write back -----------------------------------------------------------------------------------------------------
     if (!env_ok) return;
     float *odp = buf.char_dof_pos + (size_t)D_ * e, *odv = buf.char_dof_vel + (size_t)D_ * e, *ocf = buf.contact_forces + 3 * (size_t)e * B_;
+    float4 *pr = prep ? prep + (size_t)e * 16 : nullptr;
     if (w == 0) {
         const v3 out = mk(anc.x + rp.x, anc.y + rp.y, anc.z + rp.z);
         float *o = buf.char_root_pos + 3 * (size_t)e; o[0] = out.x; o[1] = out.y; o[2] = out.z;
@@ -966,13 +977,18 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
             sh[3] = rp.x - (out.x - anc.x); sh[4] = rp.y - (out.y - anc.y); sh[5] = rp.z - (out.z - anc.z);
         }
         o = buf.char_root_rot + 4 * (size_t)e; o[0] = rq.x; o[1] = rq.y; o[2] = rq.z; o[3] = rq.w;
+        if (prep) { // slot 0 of the prep record: heading terms of the new root rotation (k_env_prep, lane 0)
+            const float heading = parc::calc_heading(make_float4(rq.x, rq.y, rq.z, rq.w));
+            const float4 hinv = parc::heading_quat_inv(heading);
+            prep[(size_t)e * 16] = make_float4(cosf(heading), sinf(heading), hinv.z, hinv.w);
+        }
         o = buf.char_root_vel + 3 * (size_t)e; o[0] = rv.x; o[1] = rv.y; o[2] = rv.z;
         o = buf.char_root_ang_vel + 3 * (size_t)e; o[0] = rw.x; o[1] = rw.y; o[2] = rw.z;
     }
     PARC_UNROLL
     for (int k = 0; k < WV_MAXLEN; ++k) {
-        if (k < llen) wv_store_joint(M, W, W.body[lc][k], limb[k], odp, odv, ocf);
-        if (k < tlen) wv_store_joint(M, W, W.body[0][k], trunk[k], odp, odv, ocf);
+        if (k < llen) wv_store_joint(M, W, W.body[lc][k], limb[k], odp, odv, ocf, pr);
+        if (k < tlen) wv_store_joint(M, W, W.body[0][k], trunk[k], odp, odv, ocf, pr);
     }
 #ifdef PARC_STAMPS
     WSTAMP(10);

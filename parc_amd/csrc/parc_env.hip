@@ -242,7 +242,8 @@ __device__ __forceinline__ float lane_value(float v, int l) { return __int_as_fl
 // scalar spilled to a VGPR lane comes back as a VALU instruction).
 template <int MODE, bool MIRROR>
 __global__ __launch_bounds__(64, 4) void k_env_post(const StepParams P, const int64_t *__restrict__ env_ids,
-                                                 const int *__restrict__ env_ids32, const int *__restrict__ count_dev, int count) {
+                                                 const int *__restrict__ env_ids32, const int *__restrict__ count_dev, int count,
+                                                 unsigned long long *bump_calls) {
     // P arrives by value in the kernarg segment: its pointers are then known to be global (global_load / global_store
     // instead of flat_*, which would also tie up the LDS wait counter), its scalars are scalar loads where they are used
     extern __shared__ __align__(16) float s_obs[]; // staged observation prefix [0, off_tarc)
@@ -265,6 +266,8 @@ __global__ __launch_bounds__(64, 4) void k_env_post(const StepParams P, const in
                                                                                             // (behind the staged prefix) when the tracking error is reported
 
     const int lane = threadIdx.x;
+    // the observation pass of a sampling reset closes the call: every block of the reset kernel has read the Philox call index by now
+    if (MODE == MODE_OBS && bump_calls && blockIdx.x == 0 && lane == 0) *bump_calls += 1ull;
     if (count_dev) count = *count_dev; // device-side list (reset_done): no host round trip
     const int it = blockIdx.x;
     if (it >= count) return;
@@ -1078,6 +1081,64 @@ __global__ void k_fk(const DevTables *T, const float *root_pos, const float *roo
               bp + 3 * (size_t)i * B, br ? br + 4 * (size_t)i * B : nullptr);
 }
 
+// ---- device RNG for resets: Philox4x32-10 ---------------------------------------------------------
+__device__ __forceinline__ void philox_round(unsigned &c0, unsigned &c1, unsigned &c2, unsigned &c3, unsigned k0, unsigned k1) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
+    const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
+    const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+__device__ __forceinline__ void philox4(unsigned long long seed, unsigned long long ctr_hi, unsigned ctr_lo, float *u4) {
+    unsigned c0 = ctr_lo, c1 = (unsigned)ctr_hi, c2 = (unsigned)(ctr_hi >> 32), c3 = 0x5041524Bu;
+    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+    for (int r = 0; r < 10; ++r) { philox_round(c0, c1, c2, c3, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+    u4[0] = (c0 >> 8) * (1.0f / 16777216.0f); u4[1] = (c1 >> 8) * (1.0f / 16777216.0f);
+    u4[2] = (c2 >> 8) * (1.0f / 16777216.0f); u4[3] = (c3 >> 8) * (1.0f / 16777216.0f);
+}
+
+__device__ __forceinline__ double shfl_up_f64(double v, int d) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __shfl_up((int)(b & 0xffffffffll), d, 64), hi = __shfl_up((int)(b >> 32), d, 64);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+
+// ---- sampling of the reset state (dm_env.py:470-504), inside k_reset_with --------------------------------------------
+// The Philox call index of a sampling reset is *call_dev + 1; the observation launch that follows the reset kernel bumps
+// the device-side counter (so that a captured graph replays with a fresh index every time).
+#define CDF_LOCAL_MAX 64
+struct SampleParams {
+    int enabled;                 // 0: the caller passes motion ids / terrain ids / start times / xy noise (parc_env_reset_with)
+    int M, T, rand_reset, demo_mode;
+    float min_w, noise_scale;
+    const float *cdf_global;     // k_build_cdf's output, libraries of more than CDF_LOCAL_MAX motions
+    const float *fail_rates, *motion_weights, *start_frac;
+    unsigned long long seed;
+    const unsigned long long *call_dev;
+};
+
+__device__ __forceinline__ void sample_reset(const SampleParams &SP, const float *cdf, const MotionMeta *meta, int e, int &mid, int &tid, float &t0,
+                                             float &nx, float &ny) {
+    const unsigned long long call = *SP.call_dev + 1ull;
+    float u[4], v[4];
+    philox4(SP.seed, call, (unsigned)e * 2u, u);
+    philox4(SP.seed, call, (unsigned)e * 2u + 1u, v);
+    const int M = SP.M;
+    if (SP.demo_mode) mid = e % M; // dm_env.py:479-480
+    else { // multinomial with replacement == inverse CDF per draw (motion_lib.py:56-60)
+        const float x = u[0] * cdf[M - 1];
+        int lo = 0, hi = M - 1;
+        while (lo < hi) { const int md = (lo + hi) >> 1; if (cdf[md] > x) hi = md; else lo = md + 1; }
+        mid = lo;
+    }
+    tid = min((int)(u[1] * (float)SP.T), SP.T - 1);                                       // torch.randint(high=T)
+    const float len = meta[mid].length;
+    t0 = SP.rand_reset ? u[2] * len : len * (SP.start_frac ? SP.start_frac[e] : 0.f);     // motion_lib.py:62-72, dm_env.py:500-504
+    nx = SP.noise_scale * (v[0] * 2.0f - 1.0f);                                           // mgdm_dm_util.py:103-104
+    ny = SP.noise_scale * (v[1] * 2.0f - 1.0f);
+}
+
 // ------------------------------------------------------------------------------------------------
 // reset (dm_env.py:567-592): thread per reset env
 // ------------------------------------------------------------------------------------------------
@@ -1095,8 +1156,8 @@ struct ResetParams {
 // so results are unchanged; the per-env serial chain (15 slerps + 14 exp maps + 15-body FK, ~7k instructions) becomes ~600.
 __global__ __launch_bounds__(64) void k_reset_with(const ResetParams P, const int64_t *env_ids, const int *env_ids32, const int *count_dev, int k,
                                                    const int *motion_ids, const int *terrain_ids, const float *t0, const float *xy_noise,
-                                                   unsigned long long *bump_calls) {
-    if (bump_calls && blockIdx.x == 0 && threadIdx.x == 0) *bump_calls += 1ull; // this launch consumed the draws of call index *bump_calls + 1
+                                                   const SampleParams SP) {
+    __shared__ float s_cdf[CDF_LOCAL_MAX];
     __shared__ float4 s_q[4][16];     // [g][0] root rotation, [g][j] joint j (j >= 1)
     __shared__ float4 s_pos[4][16];   // FK: body positions
     __shared__ float4 s_rot[4][16];   // FK: body rotations
@@ -1111,9 +1172,27 @@ __global__ __launch_bounds__(64) void k_reset_with(const ResetParams P, const in
     float t = 0.f;
     Blend bl; bl.i0 = 0; bl.i1 = 0; bl.b = 0.f;
     MotionMeta meta = P.meta[0];
-    if (live) {
-        e = env_ids ? (int)env_ids[i] : (env_ids32 ? env_ids32[i] : i);
+    float nx = 0.f, ny = 0.f; // add_noise_to_char_state (mgdm_dm_util.py:102-106): xy += scale * U(-1,1)
+    if (live) e = env_ids ? (int)env_ids[i] : (env_ids32 ? env_ids32[i] : i);
+    if (SP.enabled) {
+        const float *cdf = SP.cdf_global;
+        if (SP.M <= CDF_LOCAL_MAX) { // the wave scan of k_build_cdf for a library that fits one wave: same operations, same result
+            const int lane = threadIdx.x;
+            double v = lane < SP.M ? (double)(fmaxf(SP.fail_rates[lane], SP.min_w) * SP.motion_weights[lane]) : 0.0;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const double u = shfl_up_f64(v, d); if (lane >= d) v += u; }
+            if (lane < SP.M) s_cdf[lane] = (float)(0.0 + v);
+            __syncthreads();
+            cdf = s_cdf;
+        }
+        if (live && j == 0) sample_reset(SP, cdf, P.meta, e, mid, tid, t, nx, ny); // lane 0 of the env's 16 draws, the others receive
+        mid = __shfl(mid, g * 16, 64); tid = __shfl(tid, g * 16, 64); t = __shfl(t, g * 16, 64);
+        nx = __shfl(nx, g * 16, 64); ny = __shfl(ny, g * 16, 64);
+    } else if (live) {
         mid = motion_ids[i]; tid = terrain_ids[i]; t = t0[i];
+        nx = xy_noise[2 * i]; ny = xy_noise[2 * i + 1];
+    }
+    if (live) {
         meta = P.meta[mid];
         bl = frame_blend(meta, t);
     }
@@ -1180,9 +1259,8 @@ __global__ __launch_bounds__(64) void k_reset_with(const ResetParams P, const in
             out[j] = q;
         }
     }
-    // add_noise_to_char_state (mgdm_dm_util.py:102-106): xy += scale * U(-1,1) (drawn by the caller / sampler)
     float cx = rx, cy = ry;
-    if (live) { cx = rx + xy_noise[2 * i]; cy = ry + xy_noise[2 * i + 1]; }
+    if (live) { cx = rx + nx; cy = ry + ny; }
     if (live) {
         for (int d = j; d < D; d += 16) {
             P.buf.char_dof_pos[(size_t)e * D + d] = s_dof[g][d];
@@ -1231,30 +1309,8 @@ __global__ __launch_bounds__(64) void k_reset_with(const ResetParams P, const in
     }
 }
 
-// ---- device RNG for resets: Philox4x32-10 ---------------------------------------------------------
-__device__ __forceinline__ void philox_round(unsigned &c0, unsigned &c1, unsigned &c2, unsigned &c3, unsigned k0, unsigned k1) {
-    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
-    const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
-    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
-    const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
-    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-}
-__device__ __forceinline__ void philox4(unsigned long long seed, unsigned long long ctr_hi, unsigned ctr_lo, float *u4) {
-    unsigned c0 = ctr_lo, c1 = (unsigned)ctr_hi, c2 = (unsigned)(ctr_hi >> 32), c3 = 0x5041524Bu;
-    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
-    for (int r = 0; r < 10; ++r) { philox_round(c0, c1, c2, c3, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
-    u4[0] = (c0 >> 8) * (1.0f / 16777216.0f); u4[1] = (c1 >> 8) * (1.0f / 16777216.0f);
-    u4[2] = (c2 >> 8) * (1.0f / 16777216.0f); u4[3] = (c3 >> 8) * (1.0f / 16777216.0f);
-}
-
 // weights = clamp(fail_rate, min_w) * motion_weight (dm_env.py:487-490) -> inclusive CDF (one block)
-__device__ __forceinline__ double shfl_up_f64(double v, int d) {
-    const long long b = __double_as_longlong(v);
-    const int lo = __shfl_up((int)(b & 0xffffffffll), d, 64), hi = __shfl_up((int)(b >> 32), d, 64);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-
-// Libraries of more than 64 motions; smaller ones are scanned by k_reset_sample itself (one launch less on the reset path).
+// Libraries of more than CDF_LOCAL_MAX motions; smaller ones are scanned by k_reset_with itself (one launch less on the reset path).
 __global__ __launch_bounds__(1024) void k_build_cdf(const float *fail_rates, const float *motion_weights, float min_w, int M, float *cdf) {
     // rows of 1024 consecutive motions (coalesced); inside a row: wave scans through shuffles, the 16 wave totals through LDS;
     // the running total carries from row to row.  Sums are formed in double, the stored value is its fp32 rounding.
@@ -1288,51 +1344,6 @@ __global__ __launch_bounds__(1024) void k_build_cdf(const float *fail_rates, con
             __syncthreads();
         }
     }
-}
-
-// The Philox call index of a sampling reset is *call_dev + 1; the k_reset_with launch that follows bumps the device-side counter (so
-// that a captured graph replays with a fresh index every time).
-#define CDF_LOCAL_MAX 64
-__global__ __launch_bounds__(128) void k_reset_sample(const int64_t *env_ids, const int *env_ids32, const int *count_dev, int k, int M, int T, const float *cdf_global,
-                                                      const float *fail_rates, const float *motion_weights, float min_w, const MotionMeta *meta,
-                                                      unsigned long long seed, const unsigned long long *call_dev, int rand_reset, int demo_mode, float noise_scale,
-                                                      const float *start_frac, int *motion_ids, int *terrain_ids, float *t0, float *xy_noise) {
-    __shared__ float s_cdf[CDF_LOCAL_MAX];
-    const float *cdf = cdf_global;
-    if (count_dev) k = *count_dev;
-    if ((int)(blockIdx.x * blockDim.x) >= k) return; // uniform
-    if (M <= CDF_LOCAL_MAX) { // the wave scan of k_build_cdf for a library that fits one wave: same operations, same result
-        if (threadIdx.x < 64) {
-            const int lane = threadIdx.x;
-            double v = lane < M ? (double)(fmaxf(fail_rates[lane], min_w) * motion_weights[lane]) : 0.0;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const double u = shfl_up_f64(v, d); if (lane >= d) v += u; }
-            if (lane < M) s_cdf[lane] = (float)(0.0 + v);
-        }
-        __syncthreads();
-        cdf = s_cdf;
-    }
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= k) return;
-    const int e = env_ids ? (int)env_ids[i] : (env_ids32 ? env_ids32[i] : i);
-    const unsigned long long call = *call_dev + 1ull;
-    float u[4], v[4];
-    philox4(seed, call, (unsigned)e * 2u, u);
-    philox4(seed, call, (unsigned)e * 2u + 1u, v);
-    int mid;
-    if (demo_mode) mid = e % M; // dm_env.py:479-480
-    else { // multinomial with replacement == inverse CDF per draw (motion_lib.py:56-60)
-        const float x = u[0] * cdf[M - 1];
-        int lo = 0, hi = M - 1;
-        while (lo < hi) { const int md = (lo + hi) >> 1; if (cdf[md] > x) hi = md; else lo = md + 1; }
-        mid = lo;
-    }
-    motion_ids[i] = mid;
-    terrain_ids[i] = min((int)(u[1] * (float)T), T - 1);                        // torch.randint(high=T)
-    const float len = meta[mid].length;
-    t0[i] = rand_reset ? u[2] * len : len * (start_frac ? start_frac[e] : 0.f); // motion_lib.py:62-72, dm_env.py:500-504
-    xy_noise[2 * i] = noise_scale * (v[0] * 2.0f - 1.0f);                       // mgdm_dm_util.py:103-104
-    xy_noise[2 * i + 1] = noise_scale * (v[1] * 2.0f - 1.0f);
 }
 
 // ================================================================================================
@@ -1372,8 +1383,7 @@ struct ParcEnv {
     unsigned char *d_ema = nullptr;
     int *d_done_list = nullptr, *d_done_key = nullptr, *d_chunk_count = nullptr, *d_motion_done = nullptr, *d_reset_count = nullptr;
     int nchunks = 0;
-    int *d_tmp_mid = nullptr, *d_tmp_tid = nullptr;
-    float *d_tmp_t0 = nullptr, *d_tmp_noise = nullptr, *d_scratch_jr = nullptr, *d_start_frac = nullptr;
+    float *d_scratch_jr = nullptr, *d_start_frac = nullptr;
     unsigned long long *d_reset_calls = nullptr;   // device counter of sampling resets (Philox call index)
     const float *action_bound = nullptr;           // parc_env_bind_action
     hipGraphExec_t graph_exec = nullptr;           // parc_env_step_reset_graph
@@ -1397,7 +1407,7 @@ extern "C" int parc_abi_version(void) { return PARC_ABI_VERSION; }
 
 static void free_dev(ParcEnv *e) {
     void *ptrs[] = {e->d_root_shadow, e->d_prep, e->d_dyn, e->d_coop, e->d_wave, e->d_tab, e->d_ray, e->d_env_off, e->d_hf, e->d_motion_off, e->d_records, e->d_meta, e->d_weights, e->d_fail,
-                    e->d_cdf, e->d_ema, e->d_done_list, e->d_done_key, e->d_chunk_count, e->d_motion_done, e->d_reset_count, e->d_reset_calls, e->d_tmp_mid, e->d_tmp_tid, e->d_tmp_t0, e->d_tmp_noise,
+                    e->d_cdf, e->d_ema, e->d_done_list, e->d_done_key, e->d_chunk_count, e->d_motion_done, e->d_reset_count, e->d_reset_calls,
                     e->d_scratch_jr};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &ev : e->ev) if (ev) (void)hipEventDestroy(ev);
@@ -1505,10 +1515,6 @@ extern "C" int parc_env_create(const ParcEnvConfig *cfg, ParcEnv **out) {
         (r = up((void **)&e->d_chunk_count, nullptr, sizeof(int) * 1024)) != hipSuccess ||
         (r = up((void **)&e->d_reset_count, nullptr, 2 * sizeof(int))) != hipSuccess ||
         (r = up((void **)&e->d_reset_calls, nullptr, sizeof(unsigned long long))) != hipSuccess ||
-        (r = up((void **)&e->d_tmp_mid, nullptr, sizeof(int) * N)) != hipSuccess ||
-        (r = up((void **)&e->d_tmp_tid, nullptr, sizeof(int) * N)) != hipSuccess ||
-        (r = up((void **)&e->d_tmp_t0, nullptr, sizeof(float) * N)) != hipSuccess ||
-        (r = up((void **)&e->d_tmp_noise, nullptr, sizeof(float) * 2 * N)) != hipSuccess ||
         (r = up((void **)&e->d_scratch_jr, nullptr, sizeof(float) * 4 * J * N)) != hipSuccess) {
         free_dev(e); delete e;
         return fail(PARC_ERR_HIP, std::string("device allocation failed: ") + hipGetErrorString(r));
@@ -1708,7 +1714,7 @@ static int launch_dynamics(ParcEnv *e, const float *action_dev, hipStream_t st) 
     if (e->use_wave)
         hipLaunchKernelGGL(parcdyn::k_dynamics_wave, dim3((e->N + 63) / 64), dim3(256), parcdyn::wv_lds_floats(e->h_wave.fac_total) * sizeof(float), st,
                            (const parcdyn::DynModel *)e->d_dyn, (const parcdyn::WaveTables *)e->d_wave, T, e->sp.buf, action_dev,
-                           (const float *)e->d_env_off, e->d_root_shadow, e->N);
+                           (const float *)e->d_env_off, e->d_root_shadow, e->d_prep, e->N);
     else if (e->use_coop)
         hipLaunchKernelGGL(parcdyn::k_dynamics_coop, dim3((e->N + CO_ENVS - 1) / CO_ENVS), dim3(64), 0, st, (const parcdyn::DynModel *)e->d_dyn,
                            (const parcdyn::CoopTables *)e->d_coop, T, e->sp.buf, action_dev, (const float *)e->d_env_off, e->N);
@@ -1736,19 +1742,20 @@ static int launch_curriculum(ParcEnv *e, hipStream_t st) {
 }
 
 static int launch_post(ParcEnv *e, int mode, const int64_t *ids, int count, hipStream_t st, const int *ids32 = nullptr,
-                       const int *count_dev = nullptr, bool prep_done = false) {
+                       const int *count_dev = nullptr, bool prep_done = false, unsigned long long *bump = nullptr) {
     if (count <= 0) return PARC_OK;
     const int grid = count;
+    if (mode == MODE_STEP && e->cfg.enable_dynamics && e->use_wave) prep_done = true; // k_dynamics_wave wrote the prep records with the state
     if (!prep_done) hipLaunchKernelGGL(k_env_prep, dim3((count + 3) / 4), dim3(64), 0, st, e->sp, ids, ids32, count_dev, count);
     const ParcEnvBuffers &b = e->sp.buf;
     const bool mirror = b.ref_root_pos || b.ref_root_rot || b.ref_root_vel || b.ref_root_ang_vel || b.ref_joint_rot || b.ref_dof_pos || b.ref_dof_vel ||
                         b.ref_body_pos || b.ref_contacts || b.ray_hfs || b.tracking_error;
     if (mode == MODE_STEP) {
-        if (mirror) hipLaunchKernelGGL((k_env_post<MODE_STEP, true>), dim3(grid), dim3(64), e->lds_bytes, st, e->sp, ids, ids32, count_dev, count);
-        else hipLaunchKernelGGL((k_env_post<MODE_STEP, false>), dim3(grid), dim3(64), e->lds_bytes, st, e->sp, ids, ids32, count_dev, count);
+        if (mirror) hipLaunchKernelGGL((k_env_post<MODE_STEP, true>), dim3(grid), dim3(64), e->lds_bytes, st, e->sp, ids, ids32, count_dev, count, bump);
+        else hipLaunchKernelGGL((k_env_post<MODE_STEP, false>), dim3(grid), dim3(64), e->lds_bytes, st, e->sp, ids, ids32, count_dev, count, bump);
     } else {
-        if (mirror) hipLaunchKernelGGL((k_env_post<MODE_OBS, true>), dim3(grid), dim3(64), e->lds_bytes, st, e->sp, ids, ids32, count_dev, count);
-        else hipLaunchKernelGGL((k_env_post<MODE_OBS, false>), dim3(grid), dim3(64), e->lds_bytes, st, e->sp, ids, ids32, count_dev, count);
+        if (mirror) hipLaunchKernelGGL((k_env_post<MODE_OBS, true>), dim3(grid), dim3(64), e->lds_bytes, st, e->sp, ids, ids32, count_dev, count, bump);
+        else hipLaunchKernelGGL((k_env_post<MODE_OBS, false>), dim3(grid), dim3(64), e->lds_bytes, st, e->sp, ids, ids32, count_dev, count, bump);
     }
 
     HIPCHK(hipGetLastError());
@@ -1950,8 +1957,19 @@ static ResetParams make_reset_params(ParcEnv *e) {
     return rp;
 }
 
-static int reset_with_impl(ParcEnv *e, const int64_t *ids, int32_t k, const int32_t *mids, const int32_t *tids, const float *t0,
-                           const float *noise, void *stream, unsigned long long *bump_calls) {
+static SampleParams make_sample_params(ParcEnv *e, bool enabled) {
+    SampleParams sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.enabled = enabled ? 1 : 0;
+    sp.M = e->M; sp.T = e->T; sp.rand_reset = e->cfg.rand_reset; sp.demo_mode = e->cfg.demo_mode;
+    sp.min_w = e->cfg.min_motion_weight; sp.noise_scale = e->cfg.rand_root_pos_offset_scale;
+    sp.cdf_global = e->d_cdf; sp.fail_rates = e->d_fail; sp.motion_weights = e->d_weights; sp.start_frac = e->d_start_frac;
+    sp.seed = (unsigned long long)e->cfg.seed; sp.call_dev = e->d_reset_calls;
+    return sp;
+}
+
+extern "C" int parc_env_reset_with(ParcEnv *e, const int64_t *ids, int32_t k, const int32_t *mids, const int32_t *tids, const float *t0,
+                                   const float *noise, void *stream) {
     int rc = check_ready(e);
     if (rc) return rc;
     if (k == 0) return PARC_OK;
@@ -1960,24 +1978,20 @@ static int reset_with_impl(ParcEnv *e, const int64_t *ids, int32_t k, const int3
     const int n = k < 0 ? e->N : k;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_reset_with, dim3((n + 3) / 4), dim3(64), 0, st, make_reset_params(e), k < 0 ? nullptr : ids, (const int *)nullptr,
-                       (const int *)nullptr, n, mids, tids, t0, noise, bump_calls);
+                       (const int *)nullptr, n, mids, tids, t0, noise, make_sample_params(e, false));
     HIPCHK(hipGetLastError());
-    return launch_post(e, MODE_OBS, k < 0 ? nullptr : ids, n, st, nullptr, nullptr, /*prep_done=*/true);
+    return launch_post(e, MODE_OBS, k < 0 ? nullptr : ids, n, st, nullptr, nullptr, /*prep_done=*/true); // the caller drew the samples: the sampling counter stays
 }
 
-extern "C" int parc_env_reset_with(ParcEnv *e, const int64_t *ids, int32_t k, const int32_t *mids, const int32_t *tids, const float *t0,
-                                   const float *noise, void *stream) {
-    return reset_with_impl(e, ids, k, mids, tids, t0, noise, stream, nullptr); // the caller drew the samples: the sampling counter stays
-}
-
-// motion / terrain / start time / xy noise of the envs to reset (dm_env.py:470-504): libraries of up to CDF_LOCAL_MAX motions are
-// scanned inside k_reset_sample, larger ones by k_build_cdf first
-static void launch_sample(ParcEnv *e, const int64_t *ids, const int *ids32, const int *count_dev, int n, hipStream_t st) {
+// A sampling reset (dm_env.py:470-504 + :567-592): [k_build_cdf for libraries of more than CDF_LOCAL_MAX motions,] k_reset_with drawing
+// motion / terrain / start time / xy noise per env, the observation pass (which bumps the Philox call index).
+static int sampling_reset(ParcEnv *e, const int64_t *ids, const int *ids32, const int *count_dev, int n, hipStream_t st) {
     if (e->M > CDF_LOCAL_MAX)
         hipLaunchKernelGGL(k_build_cdf, dim3(1), dim3(1024), 0, st, e->d_fail, e->d_weights, e->cfg.min_motion_weight, e->M, e->d_cdf);
-    hipLaunchKernelGGL(k_reset_sample, dim3((n + 127) / 128), dim3(128), 0, st, ids, ids32, count_dev, n, e->M, e->T, e->d_cdf, e->d_fail, e->d_weights,
-                       e->cfg.min_motion_weight, e->d_meta, (unsigned long long)e->cfg.seed, (const unsigned long long *)e->d_reset_calls, e->cfg.rand_reset,
-                       e->cfg.demo_mode, e->cfg.rand_root_pos_offset_scale, e->d_start_frac, e->d_tmp_mid, e->d_tmp_tid, e->d_tmp_t0, e->d_tmp_noise);
+    hipLaunchKernelGGL(k_reset_with, dim3((n + 3) / 4), dim3(64), 0, st, make_reset_params(e), ids, ids32, count_dev, n, (const int *)nullptr,
+                       (const int *)nullptr, (const float *)nullptr, (const float *)nullptr, make_sample_params(e, true));
+    HIPCHK(hipGetLastError());
+    return launch_post(e, MODE_OBS, ids, n, st, ids32, count_dev, /*prep_done=*/true, e->d_reset_calls);
 }
 
 extern "C" int parc_env_reset(ParcEnv *e, const int64_t *ids, int32_t k, void *stream) {
@@ -1986,10 +2000,7 @@ extern "C" int parc_env_reset(ParcEnv *e, const int64_t *ids, int32_t k, void *s
     if (k == 0) return PARC_OK;
     if (k > e->N) return fail(PARC_ERR_INVALID, "k > num_envs");
     if (k > 0 && !ids) return fail(PARC_ERR_INVALID, "env_ids is NULL");
-    const int n = k < 0 ? e->N : k;
-    launch_sample(e, k < 0 ? nullptr : ids, nullptr, nullptr, n, (hipStream_t)stream);
-    HIPCHK(hipGetLastError());
-    return reset_with_impl(e, k < 0 ? nullptr : ids, k, e->d_tmp_mid, e->d_tmp_tid, e->d_tmp_t0, e->d_tmp_noise, stream, e->d_reset_calls);
+    return sampling_reset(e, k < 0 ? nullptr : ids, nullptr, nullptr, k < 0 ? e->N : k, (hipStream_t)stream);
 }
 
 // Reset every env whose done flag was raised by the last step (base_agent.py:366-370) without the
@@ -2000,13 +2011,7 @@ extern "C" int parc_env_reset_done(ParcEnv *e, void *stream) {
     if (rc) return rc;
     if (!e->done_list_fresh) return PARC_OK;
     e->done_list_fresh = false;
-    hipStream_t st = (hipStream_t)stream;
-    const int n = e->N;
-    launch_sample(e, nullptr, e->d_done_list, e->d_reset_count + 1, n, st);
-    hipLaunchKernelGGL(k_reset_with, dim3((n + 3) / 4), dim3(64), 0, st, make_reset_params(e), (const int64_t *)nullptr, e->d_done_list,
-                       e->d_reset_count + 1, n, e->d_tmp_mid, e->d_tmp_tid, e->d_tmp_t0, e->d_tmp_noise, e->d_reset_calls);
-    HIPCHK(hipGetLastError());
-    return launch_post(e, MODE_OBS, nullptr, n, st, e->d_done_list, e->d_reset_count + 1, /*prep_done=*/true);
+    return sampling_reset(e, nullptr, e->d_done_list, e->d_reset_count + 1, e->N, (hipStream_t)stream);
 }
 
 // ---- whole control step as one hipGraph launch ----------------------------------------------------------------------
