@@ -965,6 +965,22 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
     }
     if (s_flag[15] != 0 && lane == 0) atomicAdd(&g_wave_timeouts, 1u); // (a wave that is through early may miss a later timeout of another wave: the counter is a lower bound)
     // ---- write back -----------------------------------------------------------------------------------------------------
+    // The prep-record quaternions of the trunk joints (two spherical joints for the humanoid: ~800 instructions) are formed by the
+    // helper wave, which is through earlier than wave 0: wave 0 hands their dofs over in LDS (the attach-kinematics slots are dead by now).
+    const bool hand = prep != nullptr && W.helper >= 1;
+    float *s_hand = s_attkin;
+    if (hand && w == 0) {
+        PARC_UNROLL
+        for (int k = 0; k < WV_MAXLEN; ++k) {
+            if (k < tlen && W.body[0][k] != 0) {
+                const int jt = W.c[W.body[0][k]].jtype;
+                const q4 jq = trunk[k].jq; const float hang = trunk[k].hang;
+                if (jt == DJ_SPHERICAL) { const v3 ex = qlog(jq); s_hand[(3 * k) * 64] = ex.x; s_hand[(3 * k + 1) * 64] = ex.y; s_hand[(3 * k + 2) * 64] = ex.z; }
+                else if (jt == DJ_HINGE) s_hand[(3 * k) * 64] = hang;
+            }
+        }
+        publish(7, 0);
+    }
     if (!env_ok) return;
     float *odp = buf.char_dof_pos + (size_t)D_ * e, *odv = buf.char_dof_vel + (size_t)D_ * e, *ocf = buf.contact_forces + 3 * (size_t)e * B_;
     float4 *pr = prep ? prep + (size_t)e * 16 : nullptr;
@@ -988,7 +1004,20 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
     PARC_UNROLL
     for (int k = 0; k < WV_MAXLEN; ++k) {
         if (k < llen) wv_store_joint(M, W, W.body[lc][k], limb[k], odp, odv, ocf, pr);
-        if (k < tlen) wv_store_joint(M, W, W.body[0][k], trunk[k], odp, odv, ocf, pr);
+        if (k < tlen) wv_store_joint(M, W, W.body[0][k], trunk[k], odp, odv, ocf, hand ? nullptr : pr);
+    }
+    if (hand && w == W.helper) {
+        await(7, 0);
+        PARC_UNROLL
+        for (int k = 0; k < WV_MAXLEN; ++k) {
+            const int b = W.body[0][k];
+            if (k < W.len[0] && b != 0) {
+                const int jt = W.c[b].jtype;
+                if (jt == DJ_SPHERICAL) pr[b] = parc::exp_map_to_quat(parc::mk3(s_hand[(3 * k) * 64], s_hand[(3 * k + 1) * 64], s_hand[(3 * k + 2) * 64]));
+                else if (jt == DJ_HINGE) pr[b] = parc::axis_angle_to_quat(parc::mk3(W.c[b].axis[0], W.c[b].axis[1], W.c[b].axis[2]), s_hand[(3 * k) * 64]);
+                else pr[b] = make_float4(0.f, 0.f, 0.f, 1.f);
+            }
+        }
     }
 #ifdef PARC_STAMPS
     WSTAMP(10);
