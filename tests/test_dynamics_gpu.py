@@ -318,6 +318,28 @@ def test_far_envs_integrate_as_precisely_as_near_ones(monkeypatch):
     assert abs(before[1] - expect) > abs(far - expect)         # the per-step rounding this removes (DESIGN.md quotes the numbers)
 
 
+def test_step_observation_equals_recomputed_observation_bit_for_bit():
+    """After a step the observation kernel reads the prep records (heading terms, dof -> quat of the character) that
+    k_dynamics_wave wrote with the state; parc_env_compute_obs forms them with k_env_prep from the stored state.  Same device
+    functions on the same fp32 inputs: the two observation rows must be identical bits, for every env."""
+    import torch
+    from gpu_helpers import default_config
+    from parc_amd.envs.hip_parkour_env import HipParkourEnv
+    n = 4096
+    env = HipParkourEnv(default_config(), n, "cuda:0", False, seed=5, enable_dynamics=True, mirror_ref_state=False)
+    env.reset()
+    lo, hi = env._action_bound_low, env._action_bound_high
+    g = torch.Generator(device="cuda:0"); g.manual_seed(11)
+    for it in range(6):
+        act = (0.5 * (hi + lo) + 0.3 * 0.5 * (hi - lo) * torch.randn(n, env._char_dof_pos.shape[1], device="cuda:0", generator=g)).contiguous()
+        obs, _, _, _ = env.step(act)
+        stepped = obs.clone()
+        again = env._compute_obs().clone()     # k_env_prep + the observation kernel on the state the step left behind
+        torch.cuda.synchronize()
+        assert torch.equal(stepped.view(torch.int32), again.view(torch.int32)), f"step {it}: {(stepped != again).sum().item()} values differ"
+        env.reset_done()
+
+
 def test_bench_launches_its_own_ranks_on_the_gpu():
     """`python bench.py --gpus 2` end to end on hardware: the launcher starts two fresh ranks (both on this box's one GPU:
     PARC_BENCH_SHARE_GPU, gloo for the barrier / max), each owns 4 096 of 8 192 envs (strong scaling) with the env origins of
