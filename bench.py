@@ -322,10 +322,10 @@ def worker(a):
     post_traffic = None
     pmc = _profile_json("r02_pmc_hbm_traffic.json") or _profile_json("r01_pmc_hbm_traffic.json")
     if pmc and at_profiled_cfg:
-        k = "void k_env_post<0>"
+        k = [q for q in pmc["FETCH_SIZE_KiB_avg_per_dispatch"] if q.startswith("void k_env_post<0")][0]  # the step instantiation
         post_traffic = (2.0 * pmc["FETCH_SIZE_KiB_avg_per_dispatch"][k] + pmc["WRITE_SIZE_KiB_avg_per_dispatch"][k]) * 1024.0
     post_gbs = BYTES_KINEMATIC * n_local / (post_ms * 1e-3) / 1e9
-    obs_kernel = {"kernel": "k_env_prep + k_env_post<MODE_STEP>", "bound": "hbm", "kernel_ms": post_ms, "achieved": post_gbs, "peak": HBM_PEAK_GBS,
+    obs_kernel = {"kernel": "k_env_post<MODE_STEP> (+ k_env_prep when the dynamics kernel did not write the prep records)", "bound": "hbm", "kernel_ms": post_ms, "achieved": post_gbs, "peak": HBM_PEAK_GBS,
                   "unit": "GB/s", "frac": post_gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_env_step": BYTES_KINEMATIC,
                   "traffic": post_traffic, "traffic_source": "profiles/ (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate run), not measured in this run"}
     if dynamics_on and dyn_ms >= post_ms:

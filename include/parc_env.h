@@ -301,7 +301,8 @@ int parc_env_record_frame(ParcEnv *env, void *stream);
 /* Kernel timing over a run of ordinary parc_env_step calls (what bench.py reports as the roofline's kernel duration).
  * While enabled, every step records three events on the caller's stream (before the dynamics kernel, after it, after
  * the observation kernels); nothing synchronises.  parc_env_get_kernel_timing waits for the last step, returns the
- * average duration of the dynamics kernel and of k_env_prep + k_env_post<STEP> over the steps since the last call, and
+ * average duration of the dynamics kernel and of the observation kernels (k_env_post<STEP>, preceded by k_env_prep when
+ * the dynamics kernel did not write the prep records itself) over the steps since the last call, and
  * clears the record. */
 int parc_env_set_kernel_timing(ParcEnv *env, int32_t enable);
 int parc_env_get_kernel_timing(ParcEnv *env, double *dynamics_ms_avg, double *obs_ms_avg, int32_t *steps);

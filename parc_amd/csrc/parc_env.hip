@@ -175,7 +175,9 @@ __global__ __launch_bounds__(64) void k_dynamics(const parcdyn::DynModel *__rest
 // cos/sin of the heading for the ray fan, and dof -> joint quaternion of the character (kin_char_model.py:586;
 // torch_util.py:502-530).  In the wave-per-env kernel these would run with 15 of 64 lanes (measured: +35 us at 65 536
 // envs when folded in, against the 22 us of this kernel); here all lanes are busy.  Output: a 256-byte record per env
-// (L2 / Infinity-Cache resident between the two launches).
+// (L2 / Infinity-Cache resident between the two launches).  The kernels that WRITE the state form the same record with the
+// same device functions (k_dynamics_wave after a step, k_reset_with after a reset); this kernel runs when the caller owns
+// the state (parc_env_compute_obs, physics off) or one of the fallback dynamics kernels stepped it.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_env_prep(const StepParams P, const int64_t *__restrict__ env_ids,
                                                  const int *__restrict__ env_ids32, const int *__restrict__ count_dev, int count) {
