@@ -235,7 +235,7 @@ enum {
     PARC_QOP_MUL = 0, PARC_QOP_ROTATE = 1, PARC_QOP_CONJ = 2, PARC_QOP_POS = 3, PARC_QOP_NORMALIZE3 = 4, PARC_QOP_TO_AXIS_ANGLE = 5 /* out [n][4]: axis, angle */,
     PARC_QOP_AA_TO_QUAT = 6, PARC_QOP_EXP_MAP_TO_QUAT = 7, PARC_QOP_TO_EXP_MAP = 8, PARC_QOP_DIFF_ANGLE = 9, PARC_QOP_NORMALIZE = 10,
     PARC_QOP_TO_TAN_NORM = 11, PARC_QOP_SLERP = 12, PARC_QOP_HEADING = 13, PARC_QOP_HEADING_QUAT_INV = 14, PARC_QOP_DIFF = 15,
-    PARC_QOP_ROTATE_2D = 16
+    PARC_QOP_ROTATE_2D = 16, PARC_QOP_SLERP_RR = 17 /* slerp as k_env_post evaluates it: reduced-range sin / acos polynomials, DESIGN.md 4 */
 };
 int parc_test_quat_op(int32_t op, const float *a_dev, const float *b_dev, const float *t_dev, int32_t n, float *out_dev, void *stream);
 

@@ -40,7 +40,7 @@ using namespace parc;
 #define REC_Q_VEL 20         // float4 #20 = root_vel, #21 = root_ang_vel, #22.. = dof_vel
 
 struct HierTables { // joint hierarchy.  The members up to `parent` are what every wave of k_env_post stages into LDS
-    float lt[16][4];
+    float lt[16][3];
     float lr[16][4];
     int fk_paths[PARC_MAX_FK_PATHS][PARC_MAX_FK_DEPTH];
     int key_ids[8];
@@ -243,7 +243,7 @@ __device__ __forceinline__ float lane_value(float v, int l) { return __int_as_fl
 // the training configuration.  Their pointers and null checks then leave the kernel (20+ SGPRs: the kernel is at the SGPR limit and every
 // scalar spilled to a VGPR lane comes back as a VALU instruction).
 template <int MODE, bool MIRROR>
-__global__ __launch_bounds__(64, 4) void k_env_post(const StepParams P, const int64_t *__restrict__ env_ids,
+__global__ __launch_bounds__(64, 5) void k_env_post(const StepParams P, const int64_t *__restrict__ env_ids,
                                                  const int *__restrict__ env_ids32, const int *__restrict__ count_dev, int count,
                                                  unsigned long long *bump_calls) {
     // P arrives by value in the kernarg segment: its pointers are then known to be global (global_load / global_store
@@ -254,8 +254,8 @@ __global__ __launch_bounds__(64, 4) void k_env_post(const StepParams P, const in
     __shared__ float4 s_q[8][16];   // row r: quats 0..14 (0 = root), slot 15 = root position.  Target rows (r >= 2) hold lr (x) q for the joints
     __shared__ float4 s_lq[2][16];  // rows 0, 1: lr (x) q of the joints (s_q keeps their raw quaternions for the reward)
     __shared__ float4 s_fk[80];     // FK positions: rows 0,1 all bodies [r*16+b]; target rows key slots [32+(r-2)*8+k]
-    __shared__ float4 s_cbp[16];    // simulator rigid-body positions of the character
-    __shared__ float4 s_rpo[8];     // per target row: heading-frame root offset
+    float4 *s_cbp = s_lq[0];        // simulator rigid-body positions of the character: written once the FK chains are through with s_lq
+    // (LDS budget: 5 120 B static + 3 072 B staged row = 8 192 B, i.e. 20 workgroups = 5 waves per SIMD on a CU's 160 KB)
     __shared__ float s_cdofv[PARC_MAX_DOFS];
     __shared__ float4 s_refvel[12]; // record float4 #20..: root_vel, root_ang_vel, dof_vel
     __shared__ float s_refct[16];
@@ -298,11 +298,6 @@ __global__ __launch_bounds__(64, 4) void k_env_post(const StepParams P, const in
         else if (lane == 30) src = P.buf.char_root_vel + 3 * (size_t)e;
         else if (lane == 31) src = P.buf.char_root_ang_vel + 3 * (size_t)e;
         if (src) { aux0 = src[0]; aux1 = src[1]; aux2 = src[2]; }
-    }
-    float bpx = 0.f, bpy = 0.f, bpz = 0.f;
-    if (!P.body_pos_from_fk && lane < B) {
-        const float *src = P.buf.char_body_pos + 3 * ((size_t)e * B + lane);
-        bpx = src[0]; bpy = src[1]; bpz = src[2];
     }
     const int qi = lane & 15;
     float4 prepq = make_float4(0.f, 0.f, 0.f, 1.f);
@@ -399,7 +394,6 @@ __global__ __launch_bounds__(64, 4) void k_env_post(const StepParams P, const in
         orow[P.off_cc + (lane - 32)] = n > 1e-5f ? 1.f : 0.f;
         s_cfn[lane - 32] = fminf(n, 1.0f);
     }
-    if (!P.body_pos_from_fk && lane < B) s_cbp[lane] = make_float4(bpx, bpy, bpz, 0.f);
 #pragma unroll
     for (int i = 0; i < 5; ++i) { const int idx = lane + 64 * i; if (idx < ncell) s_tile[idx] = tilev[i]; }
     __syncthreads();
@@ -496,7 +490,7 @@ __global__ __launch_bounds__(64, 4) void k_env_post(const StepParams P, const in
                     res.x = res.x + offx; // _move_to_motion_terrain dm_env.py:554
                     res.y = res.y + offy;
                 } else if (i < B) {
-                    res = slerp(A, Bv, bb);
+                    res = slerp_rr(A, Bv, bb);
                 }
             }
             if (i >= 1 && i < B) { // the FK chains multiply parent (x) (lr (x) q): the inner product is formed here, once per joint,
@@ -525,7 +519,6 @@ __global__ __launch_bounds__(64, 4) void k_env_post(const StepParams P, const in
                 } else if (i == 15 && r >= 2) {
                     const V3 rpo = quat_rotate(hinv, mk3(res.x - root_pos.x, res.y - root_pos.y, res.z - root_pos.z));
                     s_obs[base + 0] = rpo.x; s_obs[base + 1] = rpo.y; s_obs[base + 2] = rpo.z;
-                    s_rpo[r] = make_float4(rpo.x, rpo.y, rpo.z, 0.f);
                 }
             }
         }
@@ -556,6 +549,11 @@ __global__ __launch_bounds__(64, 4) void k_env_post(const StepParams P, const in
             const float vv[4] = {cA.x, cA.y, cA.z, cA.w};
             for (int k = 0; k < 4; ++k) { const int d = 4 * (c - 2) + k; if (d < D) P.buf.ref_dof_vel[(size_t)e * D + d] = vv[k]; }
         }
+    }
+    float bpx = 0.f, bpy = 0.f, bpz = 0.f; // caller-provided rigid-body positions (physics off): in flight during the FK chains
+    if (!P.body_pos_from_fk && lane < B) {
+        const float *src = P.buf.char_body_pos + 3 * ((size_t)e * B + lane);
+        bpx = src[0]; bpy = src[1]; bpz = src[2];
     }
     __syncthreads();
     STAMP(3);
@@ -590,7 +588,7 @@ __global__ __launch_bounds__(64, 4) void k_env_post(const StepParams P, const in
         }
     }
     __syncthreads();
-    if (P.body_pos_from_fk && lane < B) s_cbp[lane] = s_fk[lane];
+    if (lane < B) s_cbp[lane] = P.body_pos_from_fk ? s_fk[lane] : make_float4(bpx, bpy, bpz, 0.f);
     STAMP(4);
 
     // ================= key-body observations (ig_char_env.py:603-617, mgdm_dm_util.py:415-440) =================
@@ -604,10 +602,10 @@ __global__ __launch_bounds__(64, 4) void k_env_post(const StepParams P, const in
                 s_obs[o] = rl.x; s_obs[o + 1] = rl.y; s_obs[o + 2] = rl.z;
             } else {
                 const int r = row + 1;
-                const float4 kp = s_fk[32 + (r - 2) * 8 + s_tab.key_slot[s_tab.key_ids[kk]]], trp = s_q[r][15], rpo = s_rpo[r];
+                const float4 kp = s_fk[32 + (r - 2) * 8 + s_tab.key_slot[s_tab.key_ids[kk]]], trp = s_q[r][15];
                 const V3 rl = quat_rotate(hinv, mk3(kp.x - trp.x, kp.y - trp.y, kp.z - trp.z));
-                const int o = P.off_tar + (r - 2) * P.tar_w + 3 + 6 * B + 3 * kk;
-                s_obs[o] = rl.x + rpo.x; s_obs[o + 1] = rl.y + rpo.y; s_obs[o + 2] = rl.z + rpo.z;
+                const int tb = P.off_tar + (r - 2) * P.tar_w, o = tb + 3 + 6 * B + 3 * kk; // [tb, tb + 3): the row's root offset, staged by the row phase
+                s_obs[o] = rl.x + s_obs[tb]; s_obs[o + 1] = rl.y + s_obs[tb + 1]; s_obs[o + 2] = rl.z + s_obs[tb + 2];
             }
         }
     }
@@ -2174,6 +2172,7 @@ __global__ void k_test_quat_op(int op, const float *__restrict__ a, const float 
     case PARC_QOP_HEADING: out[i] = calc_heading(qa); break;
     case PARC_QOP_HEADING_QUAT_INV: put4(heading_quat_inv(calc_heading(qa))); break;
     case PARC_QOP_DIFF: put4(quat_mul(qb, quat_conj(qa))); break; // torch_util.py:454 quat_diff(q0, q1) = q1 (x) conj(q0)
+    case PARC_QOP_SLERP_RR: put4(slerp_rr(qa, qb, ts)); break; // the observation kernel's reduced-range variant
     case PARC_QOP_ROTATE_2D: { // torch_util.py:651, as the ray loop of k_env_post evaluates it
         const float ch = cosf(ts), sh = sinf(ts);
         out[2 * i] = qa.x * ch - qa.y * sh; out[2 * i + 1] = qa.x * sh + qa.y * ch; break;
@@ -2183,10 +2182,10 @@ __global__ void k_test_quat_op(int op, const float *__restrict__ a, const float 
 }
 
 extern "C" int parc_test_quat_op(int32_t op, const float *a, const float *b, const float *t, int32_t n, float *out, void *stream) {
-    if (!a || !out || n < 0 || op < 0 || op > PARC_QOP_ROTATE_2D) return fail(PARC_ERR_INVALID, "bad argument");
-    if ((op == PARC_QOP_MUL || op == PARC_QOP_ROTATE || op == PARC_QOP_DIFF_ANGLE || op == PARC_QOP_SLERP || op == PARC_QOP_DIFF) && !b)
+    if (!a || !out || n < 0 || op < 0 || op > PARC_QOP_SLERP_RR) return fail(PARC_ERR_INVALID, "bad argument");
+    if ((op == PARC_QOP_MUL || op == PARC_QOP_ROTATE || op == PARC_QOP_DIFF_ANGLE || op == PARC_QOP_SLERP || op == PARC_QOP_SLERP_RR || op == PARC_QOP_DIFF) && !b)
         return fail(PARC_ERR_INVALID, "this op needs a second operand");
-    if ((op == PARC_QOP_AA_TO_QUAT || op == PARC_QOP_SLERP || op == PARC_QOP_ROTATE_2D) && !t) return fail(PARC_ERR_INVALID, "this op needs the scalar operand");
+    if ((op == PARC_QOP_AA_TO_QUAT || op == PARC_QOP_SLERP || op == PARC_QOP_SLERP_RR || op == PARC_QOP_ROTATE_2D) && !t) return fail(PARC_ERR_INVALID, "this op needs the scalar operand");
     if (n == 0) return PARC_OK;
     hipLaunchKernelGGL(k_test_quat_op, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, (int)op, a, b, t, (int)n, out);
     HIPCHK(hipGetLastError());

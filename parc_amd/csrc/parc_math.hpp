@@ -146,6 +146,53 @@ __device__ __forceinline__ Q4 slerp(Q4 q0, Q4 q1, float t) {
     return r;
 }
 
+// ---- slerp with reduced-range transcendentals (the observation kernel's 105 slerps per env-step) -------------------------
+// The arguments of the reference's formula never leave [0, 1] for acos (|cos| of the half angle) and [0, pi/2] for sin
+// ((1-t) h and t h with t in [0, 1]), so the general-purpose routines' range reduction and special cases are dead weight:
+// two short polynomials do (each within 1.4e-7 relative of the exact function over the whole range: fitted and checked in
+// fp32 by tests/test_host_cpu.py; the device result is compared with the reference's slerp rows and with slerp() above by the
+// GPU tests).  Same formula, same fall-backs; ~40 instructions instead of ~170.  NOT bit-identical to slerp(): the reset path
+// and the stand-alone ops keep the accurate version.
+__device__ __forceinline__ float sin_q1(float x) { // x in [0, 1.62]
+    const float z = x * x;
+    float p = -2.4019863431590238e-08f;
+    p = fmaf(p, z, 2.753377657427336e-06f);
+    p = fmaf(p, z, -0.00019841050379909575f);
+    p = fmaf(p, z, 0.00833333283662796f);
+    p = fmaf(p, z, -0.1666666716337204f);
+    return fmaf(x * z, p, x);
+}
+__device__ __forceinline__ float acos_01(float c) { // c in [0, 1]
+    const bool big = c > 0.5f;                      // acos c = 2 asin sqrt((1-c)/2) there, pi/2 - asin c below
+    const float zb = (1.0f - c) * 0.5f;
+    const float z = big ? zb : c * c;
+    const float u = big ? __builtin_amdgcn_sqrtf(zb) : c;
+    float p = 0.03385632857680321f;                 // asin u = u + u z R(z), z = u^2 <= 0.25
+    p = fmaf(p, z, 0.01704932190477848f);
+    p = fmaf(p, z, 0.03112172894179821f);
+    p = fmaf(p, z, 0.04459759593009949f);
+    p = fmaf(p, z, 0.07500100135803223f);
+    p = fmaf(p, z, 0.1666666567325592f);
+    const float a = fmaf(u * z, p, u);
+    return big ? 2.0f * a : 1.5707963267948966f - a;
+}
+__device__ __forceinline__ Q4 slerp_rr(Q4 q0, Q4 q1, float t) {
+    float c = q0.x * q1.x + q0.y * q1.y + q0.z * q1.z + q0.w * q1.w;
+    if (c < 0.f) q1 = mk4(-q1.x, -q1.y, -q1.z, -q1.w);
+    c = fabsf(c);
+    const float cc = fminf(c, 1.0f);                // rounding can leave |c| a few ulp above 1: the last fall-back takes those
+    const float h = acos_01(cc);
+    const float s = __builtin_amdgcn_sqrtf(fmaxf(1.0f - cc * cc, 0.f));
+    const float inv = __builtin_amdgcn_rcpf(s);
+    const float ra = sin_q1((1.f - t) * h) * inv;
+    const float rb = sin_q1(t * h) * inv;
+    Q4 r = mk4(ra * q0.x + rb * q1.x, ra * q0.y + rb * q1.y, ra * q0.z + rb * q1.z, ra * q0.w + rb * q1.w);
+    if (fabsf(s) < 0.001f)
+        r = mk4(0.5f * q0.x + 0.5f * q1.x, 0.5f * q0.y + 0.5f * q1.y, 0.5f * q0.z + 0.5f * q1.z, 0.5f * q0.w + 0.5f * q1.w);
+    if (fabsf(c) >= 1.f) r = q0;
+    return r;
+}
+
 // torch_util.py:502-511
 __device__ __forceinline__ float calc_heading(Q4 q) {
     V3 d = quat_rotate_x(q);

@@ -162,7 +162,7 @@ EXPORTED_SYMBOLS = [
 # parc_test_quat_op selectors (include/parc_env.h)
 QOP = {"mul": 0, "rotate": 1, "conj": 2, "pos": 3, "normalize3": 4, "to_axis_angle": 5, "aa_to_quat": 6, "exp_map_to_quat": 7,
        "to_exp_map": 8, "diff_angle": 9, "normalize": 10, "to_tan_norm": 11, "slerp": 12, "heading": 13, "heading_quat_inv": 14,
-       "diff": 15, "rotate_2d": 16}
+       "diff": 15, "rotate_2d": 16, "slerp_rr": 17}
 REQUIRED_BUILD_FLAGS = ("-fno-slp-vectorize", "-ffp-contract=off")
 
 

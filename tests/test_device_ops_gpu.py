@@ -71,6 +71,29 @@ def test_quat_device_functions_on_the_reference_edge_rows():
     close(_qop("rotate_2d", v, t=angle, width=2), g["rotate_2d_vec"], T, "rotate_2d_vec")
 
 
+def test_reduced_range_slerp_of_the_observation_kernel():
+    """k_env_post blends its 105 quaternions per env-step with slerp_rr (acos on [0, 1] and sin on [0, pi/2] by short polynomials
+    instead of the general-purpose routines).  Against the reference's own slerp rows at the tolerance of the accurate
+    device slerp, and against that accurate slerp on 2 M random pairs incl. the near-identical / near-opposite / tiny-angle regimes
+    where the sin ratios are ill-conditioned: <= 1e-6, two decades inside the 1e-5 parity bound."""
+    g = golden("quat_ops")
+    close(_qop("slerp_rr", g["a"], g["b"], g["t"]), g["slerp"], 5e-6, "slerp_rr vs reference rows")
+    rng = np.random.default_rng(7)
+    n = 1 << 21
+    a = rng.normal(size=(n, 4)); a /= np.linalg.norm(a, axis=1, keepdims=True)
+    d = rng.normal(size=(n, 4))
+    scale = 10.0 ** rng.uniform(-7, 0.5, size=(n, 1))           # angle between the pair from 1e-7 rad to ~pi
+    b = a + scale * d; b /= np.linalg.norm(b, axis=1, keepdims=True)
+    b[: n // 8] *= -1.0                                          # the sign flip branch
+    b[n // 8: n // 8 + 1000] = a[n // 8: n // 8 + 1000]          # identical pairs: |cos| >= 1 fall-back
+    t = rng.uniform(0.0, 1.0, size=n); t[:1000] = 0.0; t[1000:2000] = 1.0
+    acc = _qop("slerp", a, b, t)
+    rr = _qop("slerp_rr", a, b, t)
+    err = np.abs(acc.astype(np.float64) - rr.astype(np.float64)).max(axis=1)
+    print({"max": float(err.max()), "p99.9": float(np.quantile(err, 0.999)), "mean": float(err.mean())})
+    assert np.isfinite(rr).all() and err.max() <= 1e-6, float(err.max())
+
+
 def _one_clip_env(tmp_path, clip_file, n, **kw):
     from gpu_helpers import default_config
     from parc_amd.envs.hip_parkour_env import HipParkourEnv
