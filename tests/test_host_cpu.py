@@ -215,3 +215,48 @@ def test_create_dataset_yaml_class_balanced_weights(tmp_path):
     assert abs(w["civilization_walk.pkl"] / w["sfu_walk.pkl"] - (254 / 30) / (15 / 30)) < 1e-9   # within a class: proportional to length
     clips = motion_lib.load_motion_file(str(tmp_path / "ds.yaml"), verbose=False)
     assert [c.name for c in clips] == [os.path.splitext(os.path.basename(m["file"]))[0] for m in y["motions"]]
+
+
+def _device_poly(fn):
+    """Coefficients of a Horner polynomial of parc_math.hpp, in evaluation order (highest degree first)."""
+    src = open(os.path.join(REPO, "parc_amd", "csrc", "parc_math.hpp")).read()
+    body = src[src.index("float " + fn + "("):]
+    body = body[:body.index("\n}\n")]
+    first = re.search(r"float p = (-?[0-9.e+-]+)f;", body).group(1)
+    rest = re.findall(r"p = fmaf\(p, z, (-?[0-9.e+-]+)f\);", body)
+    return [np.float32(first)] + [np.float32(c) for c in rest]
+
+
+def _fma32(a, b, c):  # fl32(a * b + c): the fp32 product is exact in fp64
+    return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(np.float32)
+
+
+def test_reduced_range_polynomials_of_the_observation_slerp():
+    """sin on [0, pi/2] and acos on [0, 1] as slerp_rr evaluates them (parc_math.hpp: same coefficients, same Horner order, fp32 with
+    fused multiply-adds), against the exact functions on dense grids: <= 2e-7 relative, i.e. the accuracy class of the library
+    routines they stand in for.  (The device result itself is checked by the GPU tests.)"""
+    cs = _device_poly("sin_q1")
+    x = np.linspace(0.0, 1.62, 3_000_001).astype(np.float32)
+    z = x * x
+    p = np.full_like(z, cs[0])
+    for c in cs[1:]:
+        p = _fma32(p, z, np.full_like(z, c))
+    s = _fma32(x * z, p, x)
+    ref = np.sin(x.astype(np.float64))
+    assert np.max(np.abs(s - ref)[1:] / ref[1:]) <= 2e-7
+    ca = _device_poly("acos_01")
+    c = np.linspace(0.0, 1.0, 4_000_001).astype(np.float32)
+    big = c > np.float32(0.5)
+    zb = (np.float32(1.0) - c) * np.float32(0.5)
+    z = np.where(big, zb, c * c).astype(np.float32)
+    u = np.where(big, np.sqrt(zb), c).astype(np.float32)
+    p = np.full_like(z, ca[0])
+    for q in ca[1:]:
+        p = _fma32(p, z, np.full_like(z, q))
+    a = _fma32(u * z, p, u)
+    h = np.where(big, np.float32(2.0) * a, np.float32(1.5707963267948966) - a).astype(np.float32)
+    ref = np.arccos(c.astype(np.float64))
+    err = np.abs(h - ref)
+    assert err.max() <= 2e-7
+    far = ref > 1e-4  # relative accuracy is what the sin ratios need near c -> 1
+    assert np.max(err[far] / ref[far]) <= 2e-7
