@@ -56,7 +56,9 @@ struct WaveTables {
     int par_slot[1 + WV_MAXLIMB];          // attach slot of the trunk body a limb hangs off
     int early[1 + WV_MAXLIMB];             // limb hangs off a non-root trunk body: finished before the trunk's upper part starts
     int helper;                            // wave (>= 1) of an early limb: idle in part B, it prepares own inertia + contacts of trunk bodies; -1 if none
-    int prep[WV_MAXLEN];                   // per trunk position: 1 = prepared by the helper wave (positions 0 and 1 that carry limbs)
+    int prep[WV_MAXLEN];                   // per trunk position: 1 = own inertia + contacts prepared by another wave (rec_wave), handed over as a record
+    int rec_wave[WV_MAXLEN];               // that wave (>= 1), or -1: wave 0 does the body itself.  Position 0 (the root body) is prepared AFTER the
+                                           // preparing wave's own limb (it is needed last), positions >= 1 between its limb's kinematics and inward pass
     int att_slot[WV_MAXLEN];               // per trunk position: attach slot or -1
     int nchild[WV_MAXLEN];                 // per trunk position: limbs hanging off it
     int child[WV_MAXLEN][WV_MAXLIMB];      // limb chain ids (1..)
@@ -77,11 +79,12 @@ struct WaveTables {
 #define WV_OFF_PMAX (WV_OFF_PATCH + DYN_PATCH * DYN_PATCH * 64)
 #define WV_OFF_PMAX3 (WV_OFF_PMAX + WV_PI * WV_PI * 64)
 #define WV_OFF_ROOTI (WV_OFF_PMAX3 + WV_P3 * WV_P3 * 64)
-#define WV_OFF_FLAG (WV_OFF_ROOTI + 2 * 30 * 64)   // hand-off flags between the waves of a block (see WV_F_*)
+#define WV_OFF_FLAG (WV_OFF_ROOTI + WV_MAXLEN * 30 * 64)   // hand-off flags between the waves of a block (see WV_F_*)
 // A flag holds the number of substeps for which its producer has published: a consumer of substep `sub` waits for > sub.
 #define WV_F_KIN(slot) (12 + (slot)) // wave 0: kinematics of attach slot (0..2) (+ the root position, with the root body's slot)
 #define WV_F_UP(lc) (lc)      // limb chain lc (1..4): its articulated inertia / bias handed to the trunk
-#define WV_F_REC(k) (5 + (k)) // helper wave: own inertia + contacts of trunk position k (0, 1)
+#define WV_F_REC(k) (5 + (k)) // record (own inertia + contacts) of trunk position k (0..2), prepared by wave rec_wave[k]
+#define WV_F_HAND 11           // epilogue: wave 0 has handed the trunk joints' dofs to the helper wave
 #define WV_F_ACC(slot) (8 + (slot)) // wave 0: spatial acceleration of attach slot (0..2)
 #define WV_OFF_FAC (WV_OFF_FLAG + 64)
 #define WV_LDS_FLOATS_MAX (WV_OFF_FAC + (1 + WV_MAXLIMB) * WV_MAXLEN * WV_FAC * 64)
@@ -127,7 +130,18 @@ inline bool build_wave_tables(const DynModel &M, const CoopTables &C, WaveTables
     }
     W.helper = -1;
     for (int c = 2; c < C.nchain; ++c) if (W.early[c] && W.att_slot[0] >= 0) { W.helper = c - 1; break; }
-    for (int k = 0; k < 2 && k < W.len[0]; ++k) W.prep[k] = (W.helper >= 0 && W.att_slot[k] >= 0) ? 1 : 0;
+    // Who prepares the trunk bodies' records.  Wave 0 is the critical path of a substep (its limb, then the serial chain head -> torso
+    // -> pelvis -> root solve: tools/wave_timeline.py), so every record it does not have to form itself shortens the step:
+    //   * positions that carry limbs (pelvis, torso): the helper wave, i.e. the wave of an early limb (an arm: short chain, few contacts);
+    //   * positions without limbs (the head): the wave of the LAST limb that hangs off the root (a leg: its parent kinematics arrive first),
+    //     which needs an attach slot for the position's kinematics.
+    for (int k = 0; k < WV_MAXLEN; ++k) W.rec_wave[k] = -1;
+    for (int k = 0; k < 2 && k < W.len[0]; ++k) if (W.helper >= 0 && W.att_slot[k] >= 0) W.rec_wave[k] = W.helper;
+    int root_limb = -1;
+    for (int c = 2; c < C.nchain; ++c) if (!W.early[c] && c - 1 != W.helper) root_limb = c - 1;
+    for (int k = 1; k < W.len[0]; ++k)
+        if (W.rec_wave[k] < 0 && W.att_slot[k] < 0 && root_limb >= 1 && natt < WV_MAXATT) { W.att_slot[k] = natt++; W.rec_wave[k] = root_limb; }
+    for (int k = 0; k < W.len[0]; ++k) W.prep[k] = W.rec_wave[k] >= 1 ? 1 : 0;
     int off = 0;
     for (int c = 0; c < C.nchain; ++c)
         for (int k = 0; k < W.len[c]; ++k) {
@@ -161,6 +175,15 @@ __device__ unsigned int g_wave_timeouts; // flag waits (substep loop) that hit t
 
 // Diagnostic builds only (-DPARC_STAMPS): cycles between consecutive stamp points, summed per wave role over all blocks.
 // Even slots = work segments, odd slots = the barrier wait that follows (see the WSTAMP calls in the substep loop).
+// -DPARC_TIMELINE: absolute cycle counter at the hand-off points of ONE substep (the third) of block 0, per wave: who waits for whom
+// (tools/wave_timeline.py).  A dozen s_memtime per wave and substep; separate from PARC_STAMPS, whose per-body stamps perturb more.
+#ifdef PARC_TIMELINE
+__device__ unsigned long long g_wave_tl[4][16];
+#define WTL(i) do { if (blockIdx.x == 0 && sub == 2) { const unsigned long long t_ = __builtin_readcyclecounter(); if (lane == 0) g_wave_tl[w][i] = t_; } } while (0)
+#else
+#define WTL(i) do { } while (0)
+#endif
+
 #ifdef PARC_STAMPS
 __device__ unsigned long long g_wave_stamps[4][16];
 __device__ unsigned long long g_wave_cnt[16][8]; // filled by -DPARC_COUNTS builds only: // per body: lanes, near lanes, waves with a near lane, hit lanes, hit bits, slow lanes, pass-2 iterations, waves
@@ -769,6 +792,7 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
             if (has_limb) await(WV_F_KIN(W.par_slot[lc]), sub);
         }
         WSTAMP(2);
+        WTL(0); // substep start: parent kinematics received (limbs) / own trunk kinematics done (wave 0)
         const v3 rootp = mk(s_rootp[0], s_rootp[64], s_rootp[128]);
         // ---- inward pass of this wave's limb -----------------------------------------------------------------------------
         sym6 Icl; s6 pcl = s6zero();   // carry of this wave's limb
@@ -785,6 +809,30 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
             WPIN(Icl, pcl);
             WSTAMP(14);
         };
+        // own inertia + contacts of a trunk body on behalf of wave 0, from the body's kinematics in its attach slot; the result travels as a
+        // record + flag (rec_wave in build_wave_tables says who does which)
+        auto prep_record = [&](int k) __attribute__((always_inline)) {
+            await(WV_F_KIN(W.att_slot[k]), sub);
+            const float *s = s_attkin + W.att_slot[k] * 13 * 64;
+            WvBody rb;
+            rb.bq.x = s[0]; rb.bq.y = s[64]; rb.bq.z = s[128]; rb.bq.w = s[192];
+            rb.r = mk(s[256], s[320], s[384]);
+            PARC_UNROLL
+            for (int a = 0; a < 6; ++a) rb.vel.a[a] = s[(7 + a) * 64];
+            sym6 IA; s6 pA = s6zero();
+            PARC_UNROLL
+            for (int i = 0; i < 21; ++i) IA.s[i] = 0.f;
+            WSTAMP(15);
+            wv_body_inertia(M, W, T, X, W.body[0][k], rb, qmat(rb.bq), rootp, IA, pA WSTAMP_ARGS);
+            float *sr = s_rooti + k * 30 * 64;
+            PARC_UNROLL
+            for (int i = 0; i < 21; ++i) sr[i * 64] = IA.s[i];
+            PARC_UNROLL
+            for (int a = 0; a < 6; ++a) sr[(21 + a) * 64] = pA.a[a];
+            sr[27 * 64] = rb.fcon.x; sr[28 * 64] = rb.fcon.y; sr[29 * 64] = rb.fcon.z;
+            publish(WV_F_REC(k), sub);
+            WTL(3 + k); // record of trunk position k published (5: head, 4: torso, 3: pelvis)
+        };
         if (has_limb) {
             const float *s = s_attkin + W.par_slot[lc] * 13 * 64;
             q4 pq; pq.x = s[0]; pq.y = s[64]; pq.z = s[128]; pq.w = s[192];
@@ -795,6 +843,10 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
             PARC_UNROLL
             for (int k = 0; k < WV_MAXLEN; ++k) if (k < llen) wv_fk_body(M, W, W.body[lc][k], limb[k], pq, pr, pv);
             WSTAMP(11);
+            WTL(1); // limb kinematics done
+            // records of the upper trunk bodies this wave prepares: wave 0 needs them before it needs this wave's limb
+            PARC_UNROLL
+            for (int k = WV_MAXLEN - 1; k >= 1; --k) if (w != 0 && W.rec_wave[k] == w) prep_record(k);
             PARC_UNROLL
             for (int k = WV_MAXLEN - 1; k >= 0; --k) if (k < llen) limb_body(k);
             float *u = s_up + (lc - 1) * 27 * 64;
@@ -803,34 +855,9 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
             PARC_UNROLL
             for (int a = 0; a < 6; ++a) u[(21 + a) * 64] = pcl.a[a];
             if (w != 0) publish(WV_F_UP(lc), sub); // wave 0 consumes its own limb's record in program order
+            WTL(2); // limb inward pass done, hand-over published
         }
-        // ---- helper wave: own inertia + contacts of the trunk bodies that carry limbs (their kinematics are in the attach
-        // slots).  Position 1 first: wave 0 needs it as soon as it is through with its limb and the bodies above.
-        if (w == W.helper) {
-            PARC_UNROLL
-            for (int k = 1; k >= 0; --k) {
-                if (!W.prep[k]) continue;
-                await(WV_F_KIN(W.att_slot[k]), sub);
-                const float *s = s_attkin + W.att_slot[k] * 13 * 64;
-                WvBody rb;
-                rb.bq.x = s[0]; rb.bq.y = s[64]; rb.bq.z = s[128]; rb.bq.w = s[192];
-                rb.r = mk(s[256], s[320], s[384]);
-                PARC_UNROLL
-                for (int a = 0; a < 6; ++a) rb.vel.a[a] = s[(7 + a) * 64];
-                sym6 IA; s6 pA = s6zero();
-                PARC_UNROLL
-                for (int i = 0; i < 21; ++i) IA.s[i] = 0.f;
-                WSTAMP(15);
-                wv_body_inertia(M, W, T, X, W.body[0][k], rb, qmat(rb.bq), rootp, IA, pA WSTAMP_ARGS);
-                float *sr = s_rooti + k * 30 * 64;
-                PARC_UNROLL
-                for (int i = 0; i < 21; ++i) sr[i * 64] = IA.s[i];
-                PARC_UNROLL
-                for (int a = 0; a < 6; ++a) sr[(21 + a) * 64] = pA.a[a];
-                sr[27 * 64] = rb.fcon.x; sr[28 * 64] = rb.fcon.y; sr[29 * 64] = rb.fcon.z;
-                publish(WV_F_REC(k), sub);
-            }
-        }
+        if (W.rec_wave[0] == w) prep_record(0); // the root body's record: needed last, so after this wave's own limb
         WSTAMP(3);
         // ---- wave 0: trunk inward pass, floating-base solve, trunk outward pass, integration -----------------------------
         if (w == 0) {
@@ -842,8 +869,10 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
                 const int b = W.body[0][k];
                 const m3 R = qmat(trunk[k].bq);
                 sym6 IA = Ict; s6 pA = pct;
+                WTL(3 + 3 * k); // wave 0: starts trunk position k (9: head, 6: torso, 3: pelvis)
                 if (W.prep[k]) { // prepared by the helper wave
                     await(WV_F_REC(k), sub);
+                    WTL(4 + 3 * k); // its record arrived
                     const float *sr = s_rooti + k * 30 * 64;
                     PARC_UNROLL
                     for (int i = 0; i < 21; ++i) IA.s[i] += sr[i * 64];
@@ -863,6 +892,7 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
                     PARC_UNROLL
                     for (int a = 0; a < 6; ++a) pA.a[a] += u[(21 + a) * 64];
                 }
+                WTL(5 + 3 * k); // all children of position k arrived and added
                 if (b == 0) { // floating base: solve IA a0 = -pA (Cholesky)
                     float Lm[6][6];
                     PARC_UNROLL
@@ -917,6 +947,7 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
                         PARC_UNROLL
                         for (int a = 0; a < 6; ++a) s_attacc[(slot * 6 + a) * 64] = ap.a[a];
                         publish(WV_F_ACC(slot), sub);
+                        if (k == 0) WTL(12); // pelvis acceleration published
                     }
                     if (k == 0) { // integrate the root at once: the limbs that hang off it (the long chains) then have the next
                                   // substep's kinematics of their parent before the trunk's outward pass and integration are through
@@ -942,13 +973,16 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
             PARC_UNROLL
             for (int k = 0; k < WV_MAXLEN; ++k) if (k < tlen) wv_integrate_joint(M, W, W.body[0][k], trunk[k], dt);
             WSTAMP(7);
+            WTL(13); // trunk outward + integration done
             if (sub + 1 < nsub) trunk_kinematics(sub + 1); // before this wave's own outward pass: the other limbs wait for it
+            WTL(14); // next substep's trunk kinematics published
             WSTAMP(1);
         }
         // ---- outward pass + integration of this wave's limb ----------------------------------------------------------------
         if (has_limb) {
             if (w != 0) await(WV_F_ACC(W.par_slot[lc]), sub);
             WSTAMP(8);
+            if (w != 0) WTL(6); // parent acceleration received
             s6 ap;
             PARC_UNROLL
             for (int a = 0; a < 6; ++a) ap.a[a] = s_attacc[(W.par_slot[lc] * 6 + a) * 64];
@@ -962,6 +996,7 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
             }
         }
         WSTAMP(9);
+        WTL(15); // outward pass + integration of the own limb done
     }
     if (s_flag[15] != 0 && lane == 0) atomicAdd(&g_wave_timeouts, 1u); // (a wave that is through early may miss a later timeout of another wave: the counter is a lower bound)
     // ---- write back -----------------------------------------------------------------------------------------------------
@@ -979,7 +1014,7 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
                 else if (jt == DJ_HINGE) s_hand[(3 * k) * 64] = hang;
             }
         }
-        publish(7, 0);
+        publish(WV_F_HAND, 0);
     }
     if (!env_ok) return;
     float *odp = buf.char_dof_pos + (size_t)D_ * e, *odv = buf.char_dof_vel + (size_t)D_ * e, *ocf = buf.contact_forces + 3 * (size_t)e * B_;
@@ -1007,7 +1042,7 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
         if (k < tlen) wv_store_joint(M, W, W.body[0][k], trunk[k], odp, odv, ocf, hand ? nullptr : pr);
     }
     if (hand && w == W.helper) {
-        await(7, 0);
+        await(WV_F_HAND, 0);
         PARC_UNROLL
         for (int k = 0; k < WV_MAXLEN; ++k) {
             const int b = W.body[0][k];

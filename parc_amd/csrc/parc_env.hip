@@ -2270,6 +2270,17 @@ extern "C" int parc_env_debug_wave_counts(double *out128) {
 }
 #endif
 
+#ifdef PARC_TIMELINE
+// Diagnostic (-DPARC_TIMELINE builds): absolute cycle counter at the hand-off points of one substep of block 0, [wave][event]
+extern "C" int parc_env_debug_wave_timeline(double *out64) {
+    unsigned long long h[64];
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(h, HIP_SYMBOL(parcdyn::g_wave_tl), sizeof(h)));
+    for (int i = 0; i < 64; ++i) out64[i] = (double)h[i];
+    return PARC_OK;
+}
+#endif
+
 extern "C" int parc_env_profile_step(ParcEnv *e, const float *action_dev, void *stream, int32_t iters, float *avg_ms, float *avg_post_ms) {
     int rc = check_ready(e);
     if (rc) return rc;
