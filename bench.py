@@ -71,9 +71,14 @@ def _free_port():
     return p
 
 
-def launch_ranks(n, argv, script=None, extra_env=None):
-    """Start ``n`` ranks of ``script`` (default: this file) with torchrun-style env vars, wait, return (rc, rank-0 stdout)."""
+def launch_ranks(n, argv, script=None, extra_env=None, deadline_s=None, poll_s=0.05):
+    """Start ``n`` fresh ranks of ``script`` (default: this file) with torchrun-style env vars and SUPERVISE them:
+    all children are polled; the first non-zero exit (or the overall deadline, rc 124) terminates, then kills, the
+    siblings — a rank that dies after the rendezvous must not leave the others inside a collective until the
+    NCCL / gloo timeout.  Rank 0's stdout is drained by a thread.  Returns (rc, rank-0 stdout)."""
     port = _free_port()
+    if deadline_s is None:
+        deadline_s = float(os.environ.get("PARC_BENCH_DEADLINE_S", "1500"))
     procs = []
     for r in range(n):
         env = dict(os.environ)
@@ -84,12 +89,58 @@ def launch_ranks(n, argv, script=None, extra_env=None):
             env.update(extra_env)
         procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].communicate()[0].decode()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        p.wait()
-        rc = rc or p.returncode
-    return rc, out0
+    chunks = []
+    drain = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    drain.start()
+    t_end = time.monotonic() + deadline_s
+    rc = 0
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad:
+            rc = bad[0]
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.monotonic() > t_end:
+            rc = 124
+            sys.stderr.write(f"bench.py: ranks still running after {deadline_s:.0f} s, stopping them\n")
+            break
+        time.sleep(poll_s)
+    if rc != 0:  # stop the survivors: exactly the PIDs started above
+        live = [p for p in procs if p.poll() is None]
+        for p in live:
+            p.terminate()
+        t_kill = time.monotonic() + 5.0
+        for p in live:
+            try:
+                p.wait(timeout=max(0.1, t_kill - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    drain.join(timeout=10.0)
+    return rc, (chunks[0].decode() if chunks else "")
+
+
+def _count_gpus():
+    """GPUs visible to this user WITHOUT a HIP / HSA call in the launcher process: KFD topology nodes with SIMDs, narrowed by
+    HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when they are set.  Falls back to torch's count when sysfs is not there."""
+    import glob
+    n = 0
+    for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            props = dict(ln.split()[:2] for ln in open(f).read().splitlines() if len(ln.split()) >= 2)
+            n += int(props.get("simd_count", "0")) > 0
+        except OSError:
+            pass
+    if n == 0:
+        import torch
+        return torch.cuda.device_count()
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
 
 
 def shard_sizes(envs, world, scaling):
@@ -231,12 +282,17 @@ def worker(a):
     if share:
         local = 0
     dist = None
-    if world > 1:
+    if world > 1 or a.ppo:
+        # --ppo at one rank still forms a (1-rank) process group and issues the all-reduces, so the RCCL path is loaded,
+        # executed and timed on a single GPU as well (cfg 4's collective leg)
         import torch.distributed as dist
+        kw = {}
+        if "RANK" not in os.environ:
+            kw = dict(init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"), **kw)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, **kw)
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     from parc_amd.envs.hip_parkour_env import HipParkourEnv
@@ -270,6 +326,8 @@ def worker(a):
     if a.ppo:
         grad = torch.zeros(GRAD_BUCKET_FLOATS, dtype=torch.float32, device=dev if backend == "nccl" else "cpu")
 
+    coll_events = []
+
     def one_step(i):
         if a.graph:
             env.step_and_reset_done(actions[i & 3] if dynamics_on else None)
@@ -277,10 +335,15 @@ def worker(a):
             env.step(actions[i & 3])
             env.reset_done()
         if grad is not None and (i + 1) % PPO_STEPS_PER_ITER == 0:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if grad.is_cuda else None
+            if ev:
+                ev[0].record()
             for _ in range(PPO_ALLREDUCES_PER_ITER):  # the learner's gradient bucket, once per minibatch (optimizer.py)
-                if dist is not None:
-                    dist.all_reduce(grad, op=dist.ReduceOp.SUM)
+                dist.all_reduce(grad, op=dist.ReduceOp.SUM)
                 grad.mul_(1.0 / world)
+            if ev:
+                ev[1].record()
+                coll_events.append(ev)
 
     for i in range(a.warmup):
         one_step(i)
@@ -288,6 +351,7 @@ def worker(a):
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    coll_events.clear()
     L.check(env._lib.parc_env_set_kernel_timing(env._handle, 1))  # hipEvents around the kernels of the timed steps, no sync
     t0 = time.perf_counter()
     for i in range(a.steps):
@@ -369,20 +433,30 @@ def worker(a):
                    "launch": "hipGraph (step + reset_done)" if a.graph else "stream launches"},
         "roofline": roof,
     }
+    timeouts = int(env._lib.parc_env_dynamics_timeouts(env._handle)) if dynamics_on else 0
+    out["dynamics_timeouts"] = timeouts   # LDS-flag hand-offs of k_dynamics_wave that hit their bound: must be 0
+    if a.ppo:
+        ms = [e0.elapsed_time(e1) for e0, e1 in coll_events]
+        out["collective"] = {"backend": backend, "world": world, "allreduce_bytes": GRAD_BUCKET_FLOATS * 4, "allreduces_per_iter": PPO_ALLREDUCES_PER_ITER,
+                             "iters_timed": len(ms), "ms_per_iter_leg": (sum(ms) / len(ms)) if ms else None,
+                             "note": "40 all-reduces + the 1/world scale of the flat fp32 gradient bucket, torch.cuda events on the launch stream"
+                                     + ("; one rank: RCCL's single-rank path (a device copy), exercised so the library is loaded and timed" if world == 1 else "")}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(env, a.cpu_seconds, dynamics_on, actions)
     if rank == 0:
         sys.stdout = sys.__stdout__
         print(json.dumps(out))
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
+    if timeouts:
+        sys.stderr.write(f"bench.py: rank {rank}: {timeouts} dynamics hand-off timeout(s): the measurement is void\n")
+        sys.exit(5)
 
 
 def main():
     a = parse()
     if a.gpus > 1 and "RANK" not in os.environ:  # not under torchrun: be our own launcher (no GPU call in this process)
-        import torch
-        ngpu = torch.cuda.device_count()  # does not initialise the GPU
+        ngpu = _count_gpus()
         extra = {}
         if ngpu < a.gpus:
             if not os.environ.get("PARC_BENCH_SHARE_GPU"):

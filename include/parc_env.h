@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PARC_ABI_VERSION 1
+#define PARC_ABI_VERSION 2
 #define PARC_MAX_BODIES 16   /* 15 quats + root position share one 16-lane group */
 #define PARC_MAX_DOFS 40     /* dof velocities live in floats [88,128) of a 128-float frame record */
 #define PARC_MAX_TAR_STEPS 6 /* 2 + steps skeletons <= 8 lane groups of 8 */
@@ -310,6 +310,11 @@ int parc_env_get_kernel_timing(ParcEnv *env, double *dynamics_ms_avg, double *ob
 /* name of the dynamics kernel this handle launches ("k_dynamics_wave", "k_dynamics_coop", "k_dynamics"; "" when
  * dynamics is off).  The choice follows the shape of the kinematic tree (see parc_env_create). */
 const char *parc_env_dynamics_kernel(ParcEnv *env);
+
+/* instantiation of the observation kernel the bound buffers select: "k_env_post<MODE,true>" when any optional output (the
+ * ref_* mirrors, ray_hfs, tracking_error) is bound, "k_env_post<MODE,false>" otherwise (the training / bench configuration);
+ * "" before parc_env_bind_buffers.  The parity tests assert which one they exercised. */
+const char *parc_env_post_kernel(ParcEnv *env);
 
 #ifdef __cplusplus
 }

@@ -10,7 +10,17 @@
 //   * a chain's joint state and kinematics stay in registers (k loops are fully unrolled, bodies are constants),
 //     the joint-space factors K = U D^-1 and D^-1 u park in LDS between the inward and the outward pass, laid out
 //     [slot][lane] so that every LDS access is conflict-free;
-//   * waves meet at four barriers per substep (trunk kinematics | arms + feet in | upper trunk + legs in | root + trunk out | limbs out).
+//   * the waves of a block meet at NO barrier inside the substep loop: every hand-off (parent kinematics, a limb's articulated inertia,
+//     a trunk body's record, the attach acceleration) is a record in LDS plus a flag (producer: record, release fence, flag; consumer:
+//     bounded poll with s_sleep, acquire fence, read), so a wave waits only for what it depends on.  A wait that
+//     hits its bound counts into g_wave_timeouts (parc_env_dynamics_timeouts, surfaced by HipParkourEnv.get_extra_log_info and
+//     bench.py) and the block writes NaN root positions for its envs, so the damage shows up in every finiteness check.
+// FP CONTRACTION: this header (like parc_dynamics.hpp / parc_dynamics_coop.hpp) opts INTO `fp contract(fast)` by pragma although the
+// library is built with -ffp-contract=off (which lib.load() insists on): the dynamics has no bit-exact reference (PhysX parity is
+// unpinned) and is judged at the dynamics tolerances of tests/test_dynamics_*.py; the flag protects the observation / reward path,
+// whose 1e-5 parity depends on ATen-like rounding.  The prep-record quaternions the epilogue forms call the parc:: functions of
+// parc_math.hpp, which is parsed under the command line's -ffp-contract=off: contraction is a property of the expression where it is
+// written, inlining into this kernel does not change it -- the records are bit-identical to k_env_prep's (GPU test).
 // BUILD NOTE: the library is compiled with -fno-slp-vectorize.  With SLP vectorisation on, hipcc (ROCm 7.2) produces a
 // k_dynamics_wave whose 6x6 inertias are wrong on gfx950 (entries from index 2 on; found by comparing the three dynamics
 // kernels and the CPU build, tools/dyn_cmp.py); the scalar build agrees with them to 1e-6.  The cause was not isolated:
@@ -171,7 +181,12 @@ inline bool build_wave_tables(const DynModel &M, const CoopTables &C, WaveTables
 
 #if defined(__HIPCC__)
 
-__device__ unsigned int g_wave_timeouts; // flag waits (substep loop) that hit their bound: must stay 0, see parc_env_dynamics_timeouts
+__device__ unsigned int g_wave_timeouts; // flag waits that hit their bound (exact count): must stay 0, see parc_env_dynamics_timeouts
+#ifndef PARC_FLAG_SPIN_BOUND
+#define PARC_FLAG_SPIN_BOUND (1 << 22)  // polls of one wait before it gives up (~0.3 s)
+#endif
+// -DPARC_TEST_BREAK_FLAG=<flag index>: test build (parc_amd/libparc_env_breakflag.so, tests/test_dynamics_gpu.py) whose producer
+// never publishes that flag -- every consumer of it runs into the bound; the shipped library has no such switch.
 
 // Diagnostic builds only (-DPARC_STAMPS): cycles between consecutive stamp points, summed per wave role over all blocks.
 // Even slots = work segments, odd slots = the barrier wait that follows (see the WSTAMP calls in the substep loop).
@@ -755,13 +770,17 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
     // Re-use of a record by the next substep is ordered by the same chain (e.g. a limb overwrites its hand-over only after
     // it has received the acceleration that wave 0 computed from the previous one).
     auto publish = [&](int f, int sub) __attribute__((always_inline)) {
+#ifdef PARC_TEST_BREAK_FLAG
+        if (f == (PARC_TEST_BREAK_FLAG)) return;
+#endif
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) s_flag[f] = sub + 1;
     };
     auto await = [&](int f, int sub) __attribute__((always_inline)) {
         int spins = 0;
-        while (s_flag[f] <= sub) { // bounded: a protocol error must not hang the GPU, and must not go unnoticed (s_flag[15], reported at the end)
-            if (++spins == (1 << 22)) { s_flag[15] = 1; break; }
+        while (s_flag[f] <= sub) { // bounded: a protocol error must not hang the GPU, and must not go unnoticed: the block's envs are
+                                   // poisoned at the end (s_flag[15]) and the device counter is bumped here, in the cold path only
+            if (++spins == PARC_FLAG_SPIN_BOUND) { s_flag[15] = 1; if (lane == 0) atomicAdd(&g_wave_timeouts, 1u); break; }
             __builtin_amdgcn_s_sleep(2);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -998,7 +1017,6 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
         WSTAMP(9);
         WTL(15); // outward pass + integration of the own limb done
     }
-    if (s_flag[15] != 0 && lane == 0) atomicAdd(&g_wave_timeouts, 1u); // (a wave that is through early may miss a later timeout of another wave: the counter is a lower bound)
     // ---- write back -----------------------------------------------------------------------------------------------------
     // The prep-record quaternions of the trunk joints (two spherical joints for the humanoid: ~800 instructions) are formed by the
     // helper wave, which is through earlier than wave 0: wave 0 hands their dofs over in LDS (the attach-kinematics slots are dead by now).
@@ -1053,6 +1071,14 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
                 else pr[b] = make_float4(0.f, 0.f, 0.f, 1.f);
             }
         }
+    }
+    // A flag wait of this block hit its bound: some wave integrated a stale record.  Every wave checks as its LAST action (a wave that
+    // timed out sees its own mark; wave 0, which writes the root, is through after every wave it waited for) and overwrites the root
+    // position of the block's envs with NaN: the observation kernel then produces NaN observations and rewards for them.
+    if (s_flag[15] != 0) {
+        float *o = buf.char_root_pos + 3 * (size_t)e;
+        const float qn = __builtin_nanf("");
+        o[0] = qn; o[1] = qn; o[2] = qn;
     }
 #ifdef PARC_STAMPS
     WSTAMP(10);

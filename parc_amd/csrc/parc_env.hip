@@ -1741,15 +1741,18 @@ static int launch_curriculum(ParcEnv *e, hipStream_t st) {
     return PARC_OK;
 }
 
+static bool wants_mirror(const ParcEnvBuffers &b) {
+    return b.ref_root_pos || b.ref_root_rot || b.ref_root_vel || b.ref_root_ang_vel || b.ref_joint_rot || b.ref_dof_pos || b.ref_dof_vel ||
+           b.ref_body_pos || b.ref_contacts || b.ray_hfs || b.tracking_error;
+}
+
 static int launch_post(ParcEnv *e, int mode, const int64_t *ids, int count, hipStream_t st, const int *ids32 = nullptr,
                        const int *count_dev = nullptr, bool prep_done = false, unsigned long long *bump = nullptr) {
     if (count <= 0) return PARC_OK;
     const int grid = count;
     if (mode == MODE_STEP && e->cfg.enable_dynamics && e->use_wave) prep_done = true; // k_dynamics_wave wrote the prep records with the state
     if (!prep_done) hipLaunchKernelGGL(k_env_prep, dim3((count + 3) / 4), dim3(64), 0, st, e->sp, ids, ids32, count_dev, count);
-    const ParcEnvBuffers &b = e->sp.buf;
-    const bool mirror = b.ref_root_pos || b.ref_root_rot || b.ref_root_vel || b.ref_root_ang_vel || b.ref_joint_rot || b.ref_dof_pos || b.ref_dof_vel ||
-                        b.ref_body_pos || b.ref_contacts || b.ray_hfs || b.tracking_error;
+    const bool mirror = wants_mirror(e->sp.buf);
     if (mode == MODE_STEP) {
         if (mirror) hipLaunchKernelGGL((k_env_post<MODE_STEP, true>), dim3(grid), dim3(64), e->lds_bytes, st, e->sp, ids, ids32, count_dev, count, bump);
         else hipLaunchKernelGGL((k_env_post<MODE_STEP, false>), dim3(grid), dim3(64), e->lds_bytes, st, e->sp, ids, ids32, count_dev, count, bump);
@@ -2225,6 +2228,11 @@ extern "C" float parc_env_last_dynamics_ms(ParcEnv *e) { return e ? e->last_dyn_
 extern "C" const char *parc_env_dynamics_kernel(ParcEnv *e) {
     if (!e || !e->cfg.enable_dynamics) return "";
     return e->use_wave ? "k_dynamics_wave" : (e->use_coop ? "k_dynamics_coop" : "k_dynamics");
+}
+
+extern "C" const char *parc_env_post_kernel(ParcEnv *e) {
+    if (!e || !e->bound) return "";
+    return wants_mirror(e->sp.buf) ? "k_env_post<MODE,true>" : "k_env_post<MODE,false>";
 }
 
 #ifdef PARC_STAMPS

@@ -30,6 +30,19 @@ def _device_index(device) -> int:
     return 0 if d.index is None else d.index
 
 
+def _quat_to_exp_map_np(q):
+    """torch_util.py:372 (quat_to_axis_angle :70-91, then axis * angle) on a [n, 4] xyzw array, fp32 like the reference."""
+    q = np.asarray(q, np.float32).copy()
+    q[q[:, 3] < 0] *= np.float32(-1.0)
+    ln = np.linalg.norm(q[:, :3], axis=-1).astype(np.float32)
+    angle = (np.float32(2.0) * np.arctan2(ln, q[:, 3])).astype(np.float32)
+    axis = q[:, :3] / np.maximum(ln, np.float32(1e-6))[:, None]
+    small = ln <= np.float32(1e-5)
+    angle[small] = 0.0
+    axis[small] = np.array([0.0, 0.0, 1.0], np.float32)
+    return (axis * angle[:, None]).astype(np.float32)
+
+
 class _DMView:
     """What the learner / recorder reach through ``env.get_dm_env()`` (``dm_env.py``)."""
 
@@ -95,6 +108,11 @@ class HipParkourEnv(base_env.BaseEnv):
         self._timestep = 1.0 / self._control_freq
         self._report_tracking_error = bool(env_config.get("report_tracking_error", False))
         self._output_motion_dir = env_config.get("output_motion_dir", "output/_motions/recorded_motions/")
+        # "ms_file": the motion-terrain container MotionLib loads (default); "legacy_dict": the dict the reference's recorder pickles
+        # (ig_parkour_env.py:698-736: frames / contacts / obs / obs_shapes / terrain)
+        self._record_format = env_config.get("record_format", "ms_file")
+        if self._record_format not in ("ms_file", "legacy_dict"):
+            raise ValueError("record_format must be 'ms_file' or 'legacy_dict'")
         self._rand_reset = env_config.get("rand_reset", True)
         self._demo_mode = env_config["demo_mode"]
         self._rand_root_pos_offset_scale = env_config["rand_root_pos_offset_scale"]
@@ -453,7 +471,38 @@ class HipParkourEnv(base_env.BaseEnv):
             output_motion_name = "dm_motion_" + str(env_id).zfill(3)
         os.makedirs(self._output_motion_dir, exist_ok=True)
         path = os.path.join(self._output_motion_dir, output_motion_name + ".pkl")
+        if self._record_format == "legacy_dict":
+            self._save_legacy_dict(path, rec, env_id, n, local, sliced, md.body_contacts)
+            return
         ms_file.save_ms_file(ms_file.MSFileData(motion_data=md, terrain_data=sliced.to_ms_terrain_data(), misc_data=misc), path)
+        print("wrote motion data to", path)
+        print("num frames =", n)
+
+    def _save_legacy_dict(self, path, rec, env_id, n, local_root_pos, sliced_terrain, contacts):
+        """The reference recorder's own output (ig_parkour_env.py:698-736, rows of ``_get_char_state`` :664-685): one pickled dict
+        {fps, loop_mode, frames [n, 3 + 3 + D] = localised root position | root exponential map | dofs, contacts [n, B],
+        obs, obs_shapes, terrain}.  The reference pickles its SubTerrain object under ``terrain``; here it is the same fields as
+        plain arrays (a file must not need this package's classes to load).  Root exp map / dofs are recovered from the recorded
+        quaternions with the reference's conversions (torch_util.py:70-91,372; kin_char_model.py:601 on the device)."""
+        import pickle
+        B = len(self._kin_char_model.get_body_names())
+        D = self._char_dof_pos.shape[1]
+        rows = rec.frames[:n, env_id].contiguous()
+        jr = rows[:, 7:7 + 4 * (B - 1)].contiguous()
+        dof = torch.zeros(n, D, dtype=torch.float32, device=self._device)
+        if n > 0:
+            L.check(self._lib.parc_rot_to_dof(self._handle, jr.data_ptr(), dof.data_ptr(), n, self._stream()))
+        frames = np.concatenate([np.asarray(local_root_pos, np.float32), _quat_to_exp_map_np(rows[:, 3:7].cpu().numpy()),
+                                 dof.cpu().numpy()], axis=1).astype(np.float32)
+        out = {"fps": int(self._control_freq), "loop_mode": "CLAMP", "frames": frames, "contacts": np.asarray(contacts, np.float32)}
+        if self._record_obs:
+            out["obs"] = rec.obs[:n, env_id].cpu().numpy()
+            out["obs_shapes"] = {k: {"use_normalizer": bool(v["use_normalizer"]), "shape": tuple(v["shape"])} for k, v in rec.obs_shapes.items()}
+        t = sliced_terrain
+        out["terrain"] = {"hf": np.asarray(t.hf, np.float32), "hf_maxmin": np.asarray(t.hf_maxmin, np.float32), "min_point": np.asarray(t.min_point, np.float32),
+                          "dxdy": np.asarray(t.dxdy, np.float32), "dims": np.asarray(t.hf.shape, np.int64)}
+        with open(path, "wb") as f:
+            pickle.dump(out, f)
         print("wrote motion data to", path)
         print("num frames =", n)
 
@@ -470,8 +519,25 @@ class HipParkourEnv(base_env.BaseEnv):
             info["Misc"]["Fail Rate at " + str(round(q[i].item() * 100.0)) + "% Quantile"] = at_q[i].item() * 100.0
         return info
 
+    def dynamics_timeouts(self):
+        """Flag waits of the dynamics kernel that hit their bound since the library was loaded (must be 0; synchronises the device).
+        A block that saw one wrote NaN root positions for its envs (parc_dynamics_wave.hpp)."""
+        return int(self._lib.parc_env_dynamics_timeouts(self._handle))
+
+    def check_health(self):
+        """Raise when the dynamics kernel reported a hand-off timeout: the physics of this run cannot be trusted."""
+        n = self.dynamics_timeouts()
+        if n > 0:
+            raise L.ParcError(f"k_dynamics_wave: {n} LDS-flag hand-off(s) timed out; the affected envs hold NaN root positions. "
+                              "This is a bug in the library (or a broken build), not a property of the scene: stop the run.")
+        return n
+
     def get_extra_log_info(self):
-        return dict(self._dm_extra_log_info())
+        """dm_env.py:668-727, plus the health counter of the dynamics kernel (read here = every iters_per_output iterations:
+        the query synchronises).  A non-zero counter aborts the run (scripts/run_tracker.py exits non-zero)."""
+        info = dict(self._dm_extra_log_info())
+        info["Env_Health"] = {"Dynamics_Flag_Timeouts": float(self.check_health())}
+        return info
 
     def post_test_update(self):
         return

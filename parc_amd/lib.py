@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # PARC_ENV_LIB: developer override used to A/B kernel builds; the shipped library is the in-tree one
 LIB_PATH = os.environ.get("PARC_ENV_LIB") or os.path.join(_HERE, "libparc_env.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_BODIES, MAX_DOFS, MAX_TAR_STEPS, MAX_KEY, MAX_FK_PATHS, MAX_FK_DEPTH, MAX_GEOMS = 16, 40, 6, 8, 8, 8, 24
 
 f32p = C.POINTER(C.c_float)
@@ -95,6 +95,9 @@ def load():
                            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the env step.")
     import torch  # noqa: F401  the process must hold ONE HIP runtime (torch's): load it before the library binds to libamdhip64
     lib = C.CDLL(LIB_PATH)
+    stale = f"{LIB_PATH} is a stale build (ABI mismatch): rebuild with `python -c 'import __graft_entry__ as g; g.build()'`"
+    if not hasattr(lib, "parc_abi_version") or lib.parc_abi_version() != ABI_VERSION or any(not hasattr(lib, s) for s in EXPORTED_SYMBOLS):
+        raise RuntimeError(stale)
     lib.parc_build_flags.restype = C.c_char_p
     flags = lib.parc_build_flags().decode()
     missing = [f for f in REQUIRED_BUILD_FLAGS if f not in flags.split()]
@@ -143,8 +146,8 @@ def load():
     lib.parc_env_dynamics_timeouts.argtypes = [vp]
     lib.parc_test_quat_op.argtypes = [C.c_int32, vp, vp, vp, C.c_int32, vp, vp]
     lib.parc_env_dynamics_kernel.restype = C.c_char_p
-    if lib.parc_abi_version() != ABI_VERSION:
-        raise RuntimeError("libparc_env.so ABI version mismatch")
+    lib.parc_env_post_kernel.argtypes = [vp]
+    lib.parc_env_post_kernel.restype = C.c_char_p
     _lib = lib
     return lib
 
@@ -157,6 +160,7 @@ EXPORTED_SYMBOLS = [
     "parc_rot_to_dof", "parc_forward_kinematics", "parc_calc_motion_frame", "parc_env_get_frame_vel_tables",
     "parc_env_profile_step", "parc_env_last_dynamics_ms", "parc_env_dynamics_kernel", "parc_env_set_kernel_timing", "parc_env_get_kernel_timing", "parc_env_record_bind", "parc_env_record_frame", "parc_env_set_episode_length", "parc_td_lambda_return", "parc_normalize_record", "parc_env_bind_action", "parc_env_get_buffers", "parc_env_step_reset_graph",
     "parc_test_quat_op", "parc_build_flags", "parc_env_set_never_done", "parc_env_dynamics_timeouts",
+    "parc_env_post_kernel",
 ]
 
 # parc_test_quat_op selectors (include/parc_env.h)

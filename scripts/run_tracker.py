@@ -89,6 +89,8 @@ def run(args):
         record_dm_motions(agent)
     else:
         raise AssertionError("Unsupported mode: {}".format(mode))
+    if hasattr(env, "check_health"):  # hand-off timeouts of the dynamics kernel: raises -> non-zero exit code
+        env.check_health()
 
 
 if __name__ == "__main__":

@@ -39,3 +39,22 @@ def test_launcher_reports_a_failing_rank(tmp_path):
     bad.write_text("import os, sys\nsys.exit(3 if os.environ['RANK'] == '1' else 0)\n")
     rc, _ = bench.launch_ranks(2, [], script=str(bad))
     assert rc == 3
+
+
+def test_launcher_stops_the_siblings_of_a_rank_that_dies_after_the_rendezvous():
+    """A rank that dies AFTER init_process_group leaves the others inside a collective; the launcher must return that rank's
+    code within seconds instead of waiting for the gloo / NCCL timeout."""
+    import time
+    t0 = time.time()
+    rc, out = bench.launch_ranks(3, [], script=os.path.join(REPO, "tests", "_rank_die_probe.py"))
+    assert rc == 3 and "unreachable" not in out
+    assert time.time() - t0 < 60.0
+
+
+def test_launcher_deadline(tmp_path):
+    slow = tmp_path / "slow.py"
+    slow.write_text("import time\ntime.sleep(600)\n")
+    import time
+    t0 = time.time()
+    rc, _ = bench.launch_ranks(2, [], script=str(slow), deadline_s=1.0)
+    assert rc == 124 and time.time() - t0 < 30.0

@@ -161,7 +161,8 @@ def test_weighted_sampling_with_the_fail_rate_clamp(tmp_path):
     assert np.allclose(env.get_fail_rates().numpy(), fr)  # sampling does not touch the table
 
 
-def test_cfg2_civilization_yaml_file_mode_vs_oracle(oracle, orc_char):
+@pytest.mark.parametrize("mirror", [True, False])   # False: the k_env_post<MODE, false> instantiation bench.py times
+def test_cfg2_civilization_yaml_file_mode_vs_oracle(oracle, orc_char, mirror):
     """BASELINE cfg 2: 4 096 envs, the flat-terrain walk clip, terrain_build_mode: file, kinematic-only step."""
     import torch
     from gpu_helpers import to_np
@@ -171,7 +172,8 @@ def test_cfg2_civilization_yaml_file_mode_vs_oracle(oracle, orc_char):
     n = 4096
     cfg = path_loader.load_config(os.path.join(DATA, "configs/tracker_config/dm_env_civilization.yaml"))
     assert cfg["env"]["dm"]["terrain_build_mode"] == "file" and cfg["env"]["dm"]["motion_file"].endswith("civilization.pkl")
-    env = HipParkourEnv(cfg, n, "cuda:0", False, seed=5, enable_dynamics=False)
+    env = HipParkourEnv(cfg, n, "cuda:0", False, seed=5, enable_dynamics=False, mirror_ref_state=mirror)
+    assert env._lib.parc_env_post_kernel(env._handle).decode() == ("k_env_post<MODE,true>" if mirror else "k_env_post<MODE,false>")
     sc = env._scene
     assert len(sc.clips) == 1 and np.array_equal(sc.grid.terrain.hf, sc.clips[0].terrain.hf) and not sc.grid.motion_offsets.any()
     env.reset()

@@ -364,3 +364,66 @@ def test_bench_launches_its_own_ranks_on_the_gpu():
     assert abs(d["value"] - 8192 * 20 / (d["ms_per_step"] * 20e-3)) < 1e-6 * d["value"]
     assert d["roofline"]["kernel"] == "k_dynamics_wave" and d["roofline"]["kernel_ms"] > 0 and 0 < d["roofline"]["frac"] < 1
     assert 1e6 < d["value"] < 1e9
+
+
+def test_bench_ppo_leg_runs_over_rccl_on_one_gpu():
+    """cfg 4's collective leg: `bench.py --ppo 1` at one rank forms a 1-rank `nccl` (= RCCL) process group and issues the 40 x 42.56 MB
+    gradient all-reduces every 32 steps, so the RCCL path is loaded, executed and timed on this box.
+    65 steps = two PPO iterations' worth of collectives."""
+    import json
+    import subprocess
+    import sys
+    from conftest import REPO
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "PARC_BENCH_SHARE_GPU", "PARC_BENCH_BACKEND"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--envs", "8192", "--steps", "65", "--warmup", "32",
+                        "--ppo", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.strip().startswith("{")][-1])
+    c = d["collective"]
+    assert c["backend"] == "nccl" and c["world"] == 1 and c["allreduce_bytes"] == 42555508 and c["allreduces_per_iter"] == 40
+    assert c["iters_timed"] == 2 and c["ms_per_iter_leg"] > 0.0
+    assert "all-reduces" in d["config"]["workload"] and d["dynamics_timeouts"] == 0 and d["n_gpus"] == 1
+
+
+_BREAK_BODY = r"""
+import sys, torch
+sys.path.insert(0, {repo!r}); sys.path.insert(0, {repo!r} + "/tests")
+from gpu_helpers import default_config
+from parc_amd import lib as L
+from parc_amd.envs.hip_parkour_env import HipParkourEnv
+assert L.LIB_PATH.endswith("libparc_env_breakflag.so")
+env = HipParkourEnv(default_config(), 256, "cuda:0", False, seed=5, enable_dynamics=True, mirror_ref_state=False)
+env.reset()
+assert env.dynamics_timeouts() == 0 and torch.isfinite(env._char_root_pos).all()
+obs, rew, done, info = env.step(env._char_dof_pos.clone())
+torch.cuda.synchronize()
+n_to = env.dynamics_timeouts()
+assert n_to >= 4, n_to                                     # 4 blocks x 4 substeps, wave 0 waits for the flag that is never published
+assert torch.isnan(env._char_root_pos).all()               # every block saw a timeout: every env is poisoned ...
+assert torch.isnan(obs).any(dim=1).all() and torch.isnan(rew).all()   # ... and so is what the learner would read
+try:
+    env.get_extra_log_info()
+except L.ParcError as ex:
+    assert "timed out" in str(ex)
+else:
+    raise AssertionError("get_extra_log_info() must raise when the health counter is non-zero")
+print("BREAKFLAG_OK", n_to)
+"""
+
+
+def test_flag_timeout_is_counted_and_poisons_the_state(tmp_path):
+    """A hand-off of k_dynamics_wave that never arrives (test build -DPARC_TEST_BREAK_FLAG: the producer of one LDS flag does not
+    publish; short wait bound) must not go unnoticed: the device counter counts it, the block writes NaN root positions, the
+    observation / reward of those envs are NaN, and HipParkourEnv.get_extra_log_info() raises (run_tracker.py then exits non-zero).
+    One run, in a child process (the library path is fixed at import)."""
+    import subprocess
+    import sys
+    from conftest import REPO
+    lib = os.path.join(REPO, "parc_amd", "libparc_env_breakflag.so")
+    assert os.path.exists(lib), "build it with __graft_entry__.build()"
+    script = tmp_path / "breakflag.py"
+    script.write_text(_BREAK_BODY.format(repo=REPO))
+    p = subprocess.run([sys.executable, str(script)], env=dict(os.environ, PARC_ENV_LIB=lib), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "BREAKFLAG_OK" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])

@@ -67,7 +67,8 @@ def _ops(env):
 def test_library_loaded_is_in_tree(genv):
     from parc_amd import lib as L
     assert L.LIB_PATH.endswith("parc_amd/libparc_env.so")
-    assert genv[0]._lib.parc_abi_version() == 1
+    from parc_amd import lib as L2
+    assert genv[0]._lib.parc_abi_version() == L2.ABI_VERSION == 2
 
 
 def test_kin_ops_vs_golden(genv):
@@ -185,8 +186,11 @@ def test_env_reset_vs_reference_golden(genv):
     assert np.array_equal(after, to_np(env._obs_buf))
 
 
+# mirror False = the instantiation bench.py and the learner run (k_env_post<MODE, false>: no optional ref_* / ray_hfs / tracking-error
+# outputs bound); True = the one the golden-vector tests use
+@pytest.mark.parametrize("mirror", [True, False])
 @pytest.mark.parametrize("n", [1, 100, 4096, 16384])  # 1 and 100: ragged (not a multiple of the 64-env blocks)
-def test_env_step_vs_oracle_large(tmp_path, oracle, orc_char, n):
+def test_env_step_vs_oracle_large(tmp_path, oracle, orc_char, n, mirror):
     """Same seeded state through the HIP step and the CPU oracle at cfg-2/cfg-3 env counts (from-FK bodies)."""
     import torch
     from gpu_helpers import default_config, write_motion_yaml, to_np
@@ -195,7 +199,8 @@ def test_env_step_vs_oracle_large(tmp_path, oracle, orc_char, n):
     cfg = default_config()
     w = [1.0, 1.5, 2.0, 2.5]
     cfg["env"]["dm"]["motion_file"] = write_motion_yaml(tmp_path, CLIPS4, w)
-    env = HipParkourEnv(cfg, n, "cuda:0", False, seed=7)
+    env = HipParkourEnv(cfg, n, "cuda:0", False, seed=7, mirror_ref_state=mirror)
+    assert env._lib.parc_env_post_kernel(env._handle).decode() == ("k_env_post<MODE,true>" if mirror else "k_env_post<MODE,false>")
     env.reset()
     rng = np.random.default_rng(0)
     steps = 3
@@ -246,6 +251,41 @@ def test_env_step_vs_oracle_large(tmp_path, oracle, orc_char, n):
         done_ids = torch.nonzero(env._done_buf != 0).flatten()
         env.reset(done_ids)
     assert np.isfinite(to_np(env._obs_buf)).all()
+
+
+def test_step_instantiations_bit_identical(tmp_path):
+    """k_env_post<STEP, false> (what the bench times) and k_env_post<STEP, true> (what the golden tests run) on the same state at
+    16 384 envs: observations, rewards, reward terms, done flags and fail rates must be bit-identical."""
+    import torch
+    from gpu_helpers import default_config, write_motion_yaml
+    from helpers import CLIPS4
+    from parc_amd.envs.hip_parkour_env import HipParkourEnv
+    n = 16384
+    cfg = default_config()
+    cfg["env"]["dm"]["motion_file"] = write_motion_yaml(tmp_path, CLIPS4, [1.0, 1.5, 2.0, 2.5])
+    envs = [HipParkourEnv(cfg, n, "cuda:0", False, seed=21, mirror_ref_state=m) for m in (True, False)]
+    assert [e._lib.parc_env_post_kernel(e._handle).decode() for e in envs] == ["k_env_post<MODE,true>", "k_env_post<MODE,false>"]
+    for e in envs:
+        e.reset()
+    a, b = envs
+    assert torch.equal(a._obs_buf, b._obs_buf) and torch.equal(a._motion_ids, b._motion_ids)   # the OBS instantiations after a reset
+    gen = torch.Generator(device="cuda:0"); gen.manual_seed(5)
+    for s in range(6):
+        dp = 0.03 * torch.randn(a._char_root_pos.shape, device="cuda:0", generator=gen)
+        dq = 0.05 * torch.randn(a._char_dof_pos.shape, device="cuda:0", generator=gen)
+        dv = 0.2 * torch.randn(a._char_dof_vel.shape, device="cuda:0", generator=gen)
+        f = torch.randn(a._char_contact_forces.shape, device="cuda:0", generator=gen) * \
+            (torch.rand(a._char_contact_forces[..., :1].shape, device="cuda:0", generator=gen) < 0.3)
+        for e in envs:
+            e._char_root_pos += dp; e._char_dof_pos += dq; e._char_dof_vel += dv; e._char_contact_forces[:] = f
+            e.step(None)
+        for k in ["_obs_buf", "_reward_buf", "_reward_terms", "_done_buf", "_timestep_buf", "_time_buf"]:
+            assert torch.equal(getattr(a, k), getattr(b, k)), (s, k)
+        assert np.array_equal(a.get_fail_rates().numpy(), b.get_fail_rates().numpy())
+        assert int((a._done_buf != 0).sum()) > 0 or s < 2
+        for e in envs:
+            e.reset_done()
+        assert torch.equal(a._obs_buf, b._obs_buf) and torch.equal(a._motion_ids, b._motion_ids)
 
 
 def test_full_size_properties(tmp_path):
@@ -509,6 +549,48 @@ def test_recorder_writes_motion_terrain_files(tmp_path):
         tt = T.SubTerrain.from_ms_terrain_data(f.terrain_data)
         assert tt.get_hf_val_from_points(md.root_pos[0, 0:2]) == 0.0
         assert np.isin(md.body_contacts, [0.0, 1.0]).all() and np.abs(np.linalg.norm(md.joint_rot, axis=-1) - 1.0).max() < 1e-5
+
+
+def test_recorder_legacy_dict_format(tmp_path):
+    """``record_format: legacy_dict``: the reference recorder's own output (ig_parkour_env.py:698-736; rows of _get_char_state :664-685):
+    frames [n, 34] = localised root position | root exp map | dofs, contacts [n, 15], obs, obs_shapes, terrain."""
+    import pickle
+    import torch
+    from gpu_helpers import default_config, write_motion_yaml, to_np
+    from parc_amd.envs.hip_parkour_env import HipParkourEnv, _quat_to_exp_map_np
+    cfg = default_config()
+    cfg["env"]["dm"]["motion_file"] = write_motion_yaml(tmp_path, ["sfu"], [1.0])
+    cfg["env"]["output_motion_dir"] = str(tmp_path / "rec")
+    cfg["env"]["record_format"] = "legacy_dict"
+    env = HipParkourEnv(cfg, 1, "cuda:0", False, seed=3, enable_dynamics=True, mirror_ref_state=True)
+    env.set_rand_reset(False); env.set_demo_mode(True); env.set_rand_root_pos_offset_scale(0.0)
+    env._episode_length = 1000.0
+    env._bypass_record_fail = True
+    env.reset()
+    env.build_agent_states_dict("_dm", record_obs=True)
+    env.write_agent_states()
+    dofs, rots, obs_h, cf = [to_np(env._char_dof_pos)[0].copy()], [to_np(env._char_root_rot)[0].copy()], [to_np(env._obs_buf)[0].copy()], [to_np(env._char_contact_forces)[0].copy()]
+    for it in range(200):
+        if not env.is_writing_agent_states():
+            break
+        obs, r, done, info = env.step(env._ref_dof_pos.clone())
+        dofs.append(to_np(env._char_dof_pos)[0].copy()); rots.append(to_np(env._char_root_rot)[0].copy()); obs_h.append(to_np(obs)[0].copy())
+        cf.append(to_np(env._char_contact_forces)[0].copy())
+        env.reset_done()
+    assert not env.is_writing_agent_states()
+    with open(os.path.join(str(tmp_path / "rec"), "sfu_dm.pkl"), "rb") as f:   # a file this test wrote itself
+        d = pickle.load(f)
+    assert set(d.keys()) == {"fps", "loop_mode", "frames", "contacts", "obs", "obs_shapes", "terrain"}
+    k = len(dofs)
+    assert d["fps"] == 30 and d["loop_mode"] == "CLAMP" and d["frames"].shape == (k, 34) and d["contacts"].shape == (k, 15)
+    np.testing.assert_allclose(d["frames"][:, 6:], np.stack(dofs), atol=2e-6)       # rot_to_dof(dof_to_rot(dof)) on the device
+    np.testing.assert_array_equal(d["frames"][:, 3:6], _quat_to_exp_map_np(np.stack(rots)))
+    assert abs(d["frames"][0, 0]) < 1e-6 and abs(d["frames"][0, 1]) < 1e-6           # localised: starts at the origin
+    np.testing.assert_array_equal(d["contacts"], (np.linalg.norm(np.stack(cf), axis=-1) > 1e-5).astype(np.float32))
+    np.testing.assert_array_equal(d["obs"], np.stack(obs_h))
+    assert list(d["obs_shapes"].keys()) == ["char_obs", "tar_obs", "tar_contacts", "char_contacts", "hf"]
+    t = d["terrain"]
+    assert set(t.keys()) == {"hf", "hf_maxmin", "min_point", "dxdy", "dims"} and tuple(t["dims"]) == t["hf"].shape
 
 
 def test_record_mode_driver(tmp_path):

@@ -260,3 +260,26 @@ def test_reduced_range_polynomials_of_the_observation_slerp():
     assert err.max() <= 2e-7
     far = ref > 1e-4  # relative accuracy is what the sin ratios need near c -> 1
     assert np.max(err[far] / ref[far]) <= 2e-7
+
+
+def test_read_motion_data_script_prints_the_clip(capsys):
+    """scripts/read_motion_data.py (BASELINE cfg 1's plumbing script, reference scripts/read_motion_data.py:1-20): same five prints,
+    read through the data-only decoder; values against SURVEY 8(c)'s loader sanity (sfu.pkl: 15 frames, 30 fps)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("read_motion_data", os.path.join(REPO, "scripts", "read_motion_data.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    d = mod.main(["read_motion_data.py"])
+    out = capsys.readouterr().out
+    md = d.motion_data
+    assert md.root_pos.shape == (15, 3) and md.root_rot.shape == (15, 4) and md.joint_rot.shape == (15, 14, 4) and md.body_contacts.shape == (15, 15)
+    assert md.fps == 30 and out.strip().splitlines()[-1] == "30"
+    assert str(md.root_pos) in out and str(md.body_contacts) in out
+
+
+def test_quat_to_exp_map_host_helper_matches_reference_rows():
+    """The legacy recorder format converts the recorded root quaternion with the reference's quat_to_exp_map (torch_util.py:372):
+    the numpy helper against the reference's own rows (quat_ops.npz, incl. w < 0 and tiny angles)."""
+    from parc_amd.envs.hip_parkour_env import _quat_to_exp_map_np
+    g = golden("quat_ops")
+    np.testing.assert_allclose(_quat_to_exp_map_np(g["a"]), g["quat_to_exp_map"], atol=2e-6, rtol=0)
