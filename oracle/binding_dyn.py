@@ -40,8 +40,31 @@ class DynOracle:
         self.lib.orc_dyn_get_mass(self.h, _p(mass), _p(com), _p(inertia), C.byref(total), C.byref(ncol))
         return mass, com, inertia, total.value, ncol.value
 
+    def num_segments(self):
+        return int(self.lib.orc_dyn_get_nseg(self.h))
+
+    def set_num_segments(self, n):
+        """Counterfactual for tests: 0 = collision points only (capsule end spheres, box corners)."""
+        return int(self.lib.orc_dyn_set_nseg(self.h, C.c_int(n)))
+
+    def segment_edge_point(self, hf, min_point, dxdy, a, b):
+        hf = np.ascontiguousarray(hf, np.float32)
+        a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32); q = np.zeros(4, np.float32)
+        ok = self.lib.orc_segment_edge_point(_p(hf), C.c_int(hf.shape[0]), C.c_int(hf.shape[1]), C.c_float(min_point[0]), C.c_float(min_point[1]),
+                                             C.c_float(dxdy[0]), C.c_float(dxdy[1]), _p(a), _p(b), _p(q))
+        return (q if ok else None)   # x, y, z, weight
+
     def set_gravity(self, g):
         self.lib.orc_dyn_set_gravity(self.h, C.c_float(g))
+
+    def set_ext_acc(self, ax, ay):
+        """Test hook: uniform horizontal acceleration (a tilted gravity vector)."""
+        self.lib.orc_dyn_set_ext_acc(self.h, C.c_float(ax), C.c_float(ay))
+
+    def get_contact(self):
+        out = np.zeros(4, np.float32)
+        self.lib.orc_dyn_get_contact(self.h, _p(out))
+        return dict(kn=float(out[0]), dn=float(out[1]), dtang=float(out[2]), mu=float(out[3]))
 
     def set_contact(self, kn, dn, dtang, mu):
         self.lib.orc_dyn_set_contact(self.h, C.c_float(kn), C.c_float(dn), C.c_float(dtang), C.c_float(mu))

@@ -26,6 +26,8 @@ void orc_dyn_set_contact(void *m, float kn, float dn, float dtang, float mu) {
     M->pen_cap = vmax * dn / kn;
 }
 void orc_dyn_set_gravity(void *m, float g) { ((DynModel *)m)->gravity_z = g; }
+void orc_dyn_set_ext_acc(void *m, float ax, float ay) { ((DynModel *)m)->ext_acc[0] = ax; ((DynModel *)m)->ext_acc[1] = ay; }
+void orc_dyn_get_contact(void *m, float *out4) { DynModel *M = (DynModel *)m; out4[0] = M->kn; out4[1] = M->dn; out4[2] = M->dtang; out4[3] = M->mu; }
 void orc_dyn_set_gains_scale(void *m, float s) {
     DynModel *M = (DynModel *)m;
     for (int d = 0; d < M->D; ++d) { M->kp[d] *= s; M->kd[d] *= s; }
@@ -48,6 +50,19 @@ float orc_own_column_contact(const float *tops5, float x, float y, float z, floa
         return ox == 1 ? tops5[1] : (ox == -1 ? tops5[2] : (oy == 1 ? tops5[3] : tops5[4])); }, n);
     n_out[0] = n.x; n_out[1] = n.y; n_out[2] = n.z;
     return pen;
+}
+
+int orc_dyn_get_nseg(void *m) { return ((DynModel *)m)->nseg; }
+// counterfactual for the tests: drop the collision segments (points only, the round-2 contact geometry); returns the old count
+int orc_dyn_set_nseg(void *m, int n) { DynModel *M = (DynModel *)m; const int old = M->nseg; M->nseg = n; return old; }
+
+// geometry of segment_edge_point on a heightfield: returns 1 and Q (x, y, z, weight) when the segment A-B has an edge candidate
+int orc_segment_edge_point(const float *hf, int X, int Y, float min_x, float min_y, float dx, float dy, const float *A, const float *B, float *Q_out) {
+    DynTerrain T; T.hf = hf; T.X = X; T.Y = Y; T.min_x = min_x; T.min_y = min_y; T.dx = dx; T.dy = dy;
+    v3 Q = mk(0.f, 0.f, 0.f);
+    const float w = segment_edge_point(T, mk(A[0], A[1], A[2]), mk(B[0], B[1], B[2]), [&](int ix, int iy) { return hf_at(T, ix, iy); }, Q);
+    Q_out[0] = Q.x; Q_out[1] = Q.y; Q_out[2] = Q.z; Q_out[3] = w;
+    return w > 0.f ? 1 : 0;
 }
 
 // state arrays are [n][...] row-major like the env tensors

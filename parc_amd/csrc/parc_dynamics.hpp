@@ -60,6 +60,7 @@ namespace parcdyn {
 #define DYN_MAXB 16
 #define DYN_MAXD 40
 #define DYN_MAXC 48
+#define DYN_MAXS 24  // collision segments (capsule axes, sole edges of boxes)
 #define DYN_PATCH 9 // local height patch (cells) around the root
 
 enum { DJ_ROOT = 0, DJ_HINGE = 1, DJ_SPHERICAL = 2, DJ_FIXED = 3 };
@@ -79,6 +80,14 @@ struct DynModel {
     int col_body[DYN_MAXC];
     float col_pos[DYN_MAXC][3];  // body frame
     float col_r[DYN_MAXC];
+    // collision SEGMENTS: a capsule's axis (radius seg_r) or one of the two long sole edges of a box (a thin capsule, radius 1 cm).  The points above test a
+    // capsule's two end spheres / a box's corners; a segment adds the contact of the shaft (edge) with a column's top EDGE where it
+    // crosses a grid line between two columns of different height (segment_edge_point): a shin lying across a platform edge, a sole
+    // that comes down on the lip of a step between its corners.  Sorted by body like the points.
+    int nseg;
+    int seg_body[DYN_MAXS];
+    float seg_a[DYN_MAXS][3], seg_b[DYN_MAXS][3];  // end points, body frame
+    float seg_r[DYN_MAXS];
     float gravity_z, dt;         // dt of one solver substep
     int nsub;                    // substeps per control step (sim_steps * substeps)
     float kn, dn, dtang, mu;     // contact stiffness / normal damping / tangential damping / friction
@@ -86,6 +95,9 @@ struct DynModel {
     float lim_k, lim_d;          // joint-limit penalty
     float max_ang_vel, ang_damping;
     float total_mass;
+    float ext_acc[2];            // TEST HOOK of the host build (oracle/dyn_oracle.cpp): uniform horizontal acceleration, i.e. a tilted gravity
+                                 // vector (a slope without tilting the heightfield).  Always 0 in the library: fill_dyn_model zeroes it and
+                                 // only this header's reference statement reads it.
 };
 
 struct DynTerrain {
@@ -289,23 +301,78 @@ PARC_HD float own_column_contact(const DynTerrain &T, v3 s, float r, int ix, int
     return pen + r;
 }
 
+// Where a collision segment A-B (same frame as the terrain T) meets the top edge of a column.  Every convex edge of the blocky terrain
+// lies on a grid line between two cells (the reference's mesh: one quad per cell plus vertical walls, terrain_util.py:1120-1184).  If
+// the segment's footprint crosses such a line and the two columns there differ in height, the edge {line, z = higher top} exists, and
+// the point of the segment closest to that edge LINE is where a contact would be: returns it in Q.  The caller then tests a sphere of
+// the segment's radius centred at Q against the columns around it like any other collision point (for an axis point outside the
+// solid that is the sphere-vs-edge distance, exact; for one inside -- a radius-0 sole edge cutting the corner -- the own-column rule).
+// One candidate per segment: per axis the crossed line next to the midpoint's cell, of the two axes the candidate closer to its edge.
+// The ends of a segment are collision points themselves (end spheres, box corners): the candidate's contact is WEIGHTED by
+// w = clamp(10 min(t, 1 - t), 0, 1) of its position t along the segment -- full strength over the middle 80 %, fading to nothing at
+// the ends, where the point that sits there takes over.  A hard cut-off instead makes a contact of finite strength appear when an end
+// moves a millimetre past a lip (measured: the three kernels then disagree on single envs by 100 N).
+// `top_at(ix, iy)` returns the column top of cell (ix, iy).  Returns w (0 = no candidate).
+template <class TopAt>
+PARC_HD float segment_edge_point(const DynTerrain &T, v3 A, v3 Bv, TopAt top_at, v3 &Q) {
+    // Straight-line code (both axes are always evaluated, validity is a flag): on the GPU all four height look-ups of a segment are
+    // then in flight together.  Horizontal coordinates in cell units: u = (p - min) / d, cell index = rint(u).
+    const v3 d = Bv - A;
+    const float inv[2] = {DYN_RCP(T.dx), DYN_RCP(T.dy)}, dd[2] = {T.dx, T.dy};
+    const float ua[2] = {(A.x - T.min_x) * inv[0], (A.y - T.min_y) * inv[1]}, ub[2] = {(Bv.x - T.min_x) * inv[0], (Bv.y - T.min_y) * inv[1]};
+    float ts_[2], d2_[2];
+    bool ok_[2];
+    PARC_UNROLL
+    for (int axis = 0; axis < 2; ++axis) {
+        const int o = 1 - axis;
+        const float ca = rintf(ua[axis]), cb = rintf(ub[axis]);
+        const bool cross = ca != cb;
+        const float sg = cb > ca ? 1.f : -1.f;
+        const float cm = rintf(0.5f * (ua[axis] + ub[axis]));
+        const float c0 = cm == cb ? cb - sg : cm;                 // the line between cells c0 and c0 + sg lies between the two ends
+        const float lb = c0 + 0.5f * sg;
+        const float du = ub[axis] - ua[axis];
+        const float tc = cross ? (lb - ua[axis]) * DYN_RCP(du) : 0.f;
+        const float po = ua[o] + tc * (ub[o] - ua[o]);            // the other horizontal coordinate where the line is crossed
+        const float lim = 1.0e6f;
+        const float c0c = c0 < -lim ? -lim : (c0 > lim ? lim : c0), poc = po < -lim ? -lim : (po > lim ? lim : po);
+        const int i0 = (int)c0c, i1 = (int)(c0c + sg), io = (int)rintf(poc);
+        const float t0 = axis == 0 ? top_at(i0, io) : top_at(io, i0), t1 = axis == 0 ? top_at(i1, io) : top_at(io, i1);
+        const float df = t0 - t1;
+        const bool edge = (df < 0.f ? -df : df) >= 1e-3f;         // the same height on both sides: no edge at this line
+        const float top = t0 > t1 ? t0 : t1;
+        const float da = du * dd[axis], ea = (ua[axis] - lb) * dd[axis], ez = A.z - top;
+        const float ts = -(ea * da + ez * d.z) * DYN_RCP(da * da + d.z * d.z);
+        const float qa = ea + ts * da, qz = ez + ts * d.z;
+        ts_[axis] = ts; d2_[axis] = qa * qa + qz * qz;
+        ok_[axis] = cross && edge && ts > 0.f && ts < 1.f;
+    }
+    const bool use1 = ok_[1] && (!ok_[0] || d2_[1] < d2_[0]);
+    const float ts = use1 ? ts_[1] : ts_[0];
+    Q = A + ts * d;
+    float w = 10.f * (ts < 1.f - ts ? ts : 1.f - ts);
+    w = w > 1.f ? 1.f : w;
+    return (ok_[0] || ok_[1]) ? w : 0.f;
+}
+
 // One contact (point at x relative to O with velocity vpt, penetration pen along the unit normal n): explicit force into
 // pA and the force report, implicit term dt X^T (beta 1 + (bn - beta) n n^T) X into IA.
-PARC_HD void contact_apply(const DynModel &M, float dt, v3 x, v3 vpt, float pen, v3 n, sym6 &IA, s6 &pA, v3 &fsum) {
+// `w` scales the contact's stiffness and damping (1 for a collision point; the position weight of a segment's edge candidate).
+PARC_HD void contact_apply(const DynModel &M, float dt, v3 x, v3 vpt, float pen, v3 n, sym6 &IA, s6 &pA, v3 &fsum, float w = 1.f) {
     const bool capped = pen > M.pen_cap;
     if (capped) pen = M.pen_cap;
     const float vn = dot(vpt, n);
-    float fn = M.kn * pen - M.dn * vn;
+    float fn = w * (M.kn * pen - M.dn * vn);
     if (fn < 0.f) fn = 0.f;
     const v3 vt = vpt - vn * n;
     const float vtm = DYN_SQRT(dot(vt, vt));
-    float beta = M.dtang;
+    float beta = w * M.dtang;
     if (beta * vtm > M.mu * fn) beta = vtm > 1e-9f ? M.mu * fn * DYN_RCP(vtm) : 0.f; // secant of the Coulomb cone
     const v3 f = fn * n - beta * vt;
     const v3 no = cross(x, f);
     pA.a[0] -= no.x; pA.a[1] -= no.y; pA.a[2] -= no.z; pA.a[3] -= f.x; pA.a[4] -= f.y; pA.a[5] -= f.z;
     fsum = fsum + f;
-    const float bn = fn > 0.f ? (M.dn + (capped ? 0.f : dt * M.kn)) : 0.f; // only while pushing; a saturated spring adds no stiffness
+    const float bn = fn > 0.f ? w * (M.dn + (capped ? 0.f : dt * M.kn)) : 0.f; // only while pushing; a saturated spring adds no stiffness
     add_inertia(IA, dt * beta, x, nullptr);
     symrank1(IA, dt * (bn - beta), s6mk(cross(x, n), n));
 }
@@ -389,18 +456,16 @@ PARC_HD void dyn_control_step(const DynModel &M, const DynTerrain &T, const DynS
             s6 Iv = symmul(IA[i], vel[i]);
             pA[i] = crf(vel[i], Iv);
             // gravity at the COM
-            v3 fg = mk(0.f, 0.f, M.mass[i] * M.gravity_z);
+            v3 fg = mk(M.mass[i] * M.ext_acc[0], M.mass[i] * M.ext_acc[1], M.mass[i] * M.gravity_z);
             v3 ng = cross(c, fg);
             pA[i].a[0] -= ng.x; pA[i].a[1] -= ng.y; pA[i].a[2] -= ng.z; pA[i].a[3] -= fg.x; pA[i].a[4] -= fg.y; pA[i].a[5] -= fg.z;
             fcon[i] = mk(0.f, 0.f, 0.f);
         }
         // ---- contacts: explicit force + implicit (dt*B) inertia term ----------------------------------------
         // remembered per active contact for the force report: body, arm x, B-matrix pieces
-        for (int k = 0; k < M.ncol; ++k) {
-            const int i = M.col_body[k];
-            v3 x = r[i] + mulv(R[i], mk(M.col_pos[k][0], M.col_pos[k][1], M.col_pos[k][2])); // relative to O
-            v3 g = mk(x.x + rp.x + env_off[0], x.y + rp.y + env_off[1], x.z + rp.z + env_off[2]);
-            const float rad = M.col_r[k];
+        // one collision sphere (centre x relative to O = g in global coordinates, radius rad) of body i against the column of its own
+        // cell and the higher neighbours
+        auto sphere_contacts = [&](int i, v3 x, v3 g, float rad, float w) {
             const int ix = cell_of(g.x, T.min_x, T.dx), iy = cell_of(g.y, T.min_y, T.dy);
             const float top0 = patch_h(T, patch, ix, iy);
             v3 vpt = s6lin(vel[i]) + cross(s6ang(vel[i]), x);
@@ -415,8 +480,23 @@ PARC_HD void dyn_control_step(const DynModel &M, const DynTerrain &T, const DynS
                                       : sphere_vs_column(T, g, rad, jx, jy, top, n);
                 if (!(pen > 0.f)) continue;
                 // explicit force + implicit part dt * X^T (beta 1 + (bn - beta) n n^T) X, bn = dn + dt*kn (only while pushing)
-                contact_apply(M, dt, x, vpt, pen, n, IA[i], pA[i], fcon[i]);
+                contact_apply(M, dt, x, vpt, pen, n, IA[i], pA[i], fcon[i], w);
             }
+        };
+        const v3 goff = mk(rp.x + env_off[0], rp.y + env_off[1], rp.z + env_off[2]);
+        for (int k = 0; k < M.ncol; ++k) {
+            const int i = M.col_body[k];
+            const v3 x = r[i] + mulv(R[i], mk(M.col_pos[k][0], M.col_pos[k][1], M.col_pos[k][2])); // relative to O
+            sphere_contacts(i, x, x + goff, M.col_r[k], 1.f);
+        }
+        // shafts of capsules / sole edges of boxes against the top edges of the columns (segment_edge_point)
+        for (int k = 0; k < M.nseg; ++k) {
+            const int i = M.seg_body[k];
+            const v3 xa = r[i] + mulv(R[i], mk(M.seg_a[k][0], M.seg_a[k][1], M.seg_a[k][2]));
+            const v3 xb = r[i] + mulv(R[i], mk(M.seg_b[k][0], M.seg_b[k][1], M.seg_b[k][2]));
+            v3 Q;
+            const float w = segment_edge_point(T, xa + goff, xb + goff, [&](int ix, int iy) { return patch_h(T, patch, ix, iy); }, Q);
+            if (w > 0.f) sphere_contacts(i, Q - goff, Q, M.seg_r[k], w);
         }
         // ---- inward pass ------------------------------------------------------------------------------------
         float Dinv[DYN_MAXB][6]; // symmetric 3x3 inverse: xx yy zz xy xz yz (hinge uses [0])
@@ -515,7 +595,7 @@ PARC_HD void dyn_control_step(const DynModel &M, const DynTerrain &T, const DynS
             for (int j = 0; j < 6; ++j) {
                 float sd = sget(IA[0], j, j);
                 for (int k = 0; k < j; ++k) sd -= L[j][k] * L[j][k];
-                sd = sd > 1e-12f ? sqrtf(sd) : 1e-6f;
+                sd = sd > 1e-12f ? sqrtf(sd) : 1e3f; // a non-positive pivot is a numerical breakdown: treat the direction as immovable (no acceleration) rather than as massless
                 L[j][j] = sd;
                 for (int a = j + 1; a < 6; ++a) {
                     float sa = sget(IA[0], a, j);
@@ -606,7 +686,13 @@ inline void build_mass_and_collision(DynModel &M, const GeomIn *g, int ng) {
     double m[DYN_MAXB] = {0}, mc[DYN_MAXB][3] = {{0}};
     struct Part { int body; double mass; double c[3]; double I[3][3]; };
     Part parts[64]; int np = 0;
-    M.ncol = 0;
+    M.ncol = 0; M.nseg = 0;
+    auto add_seg = [&](int body, const double *a, const double *b, double r) {
+        if (M.nseg >= DYN_MAXS) return;
+        M.seg_body[M.nseg] = body; M.seg_r[M.nseg] = (float)r;
+        for (int q = 0; q < 3; ++q) { M.seg_a[M.nseg][q] = (float)a[q]; M.seg_b[M.nseg][q] = (float)b[q]; }
+        M.nseg++;
+    };
     for (int k = 0; k < ng && np < 64; ++k) {
         Part P; P.body = g[k].body;
         for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) P.I[a][b] = 0.0;
@@ -627,6 +713,19 @@ inline void build_mass_and_collision(DynModel &M, const GeomIn *g, int ng) {
                 M.col_pos[M.ncol][2] = g[k].pos[2] + ((q & 4) ? (float)c : -(float)c);
                 M.col_r[M.ncol] = 0.f; M.ncol++;
             }
+            // the two LONG edges of the sole (the face at the body frame's lowest z; the MJCF's feet point their soles down in the rest pose),
+            // as thin capsules: radius rho = 1 cm, axis inset by rho, so their surface touches the sole plane and the box's long sides.
+            // A lip that runs across the foot -- a step approached head on -- crosses both; the short edges (toe / heel, 9 cm for the
+            // humanoid) span less than the corners already resolve.  (A radius-0 segment would put its candidate exactly ON the grid line
+            // that carries the lip: which of the two columns it is tested against would be decided by rounding.)
+            const bool long_x = a >= b;
+            const double rho = 0.01 < c ? 0.01 : c;
+            for (int q = 0; q < 2; ++q) {
+                const double sgn = q == 0 ? -1.0 : 1.0;
+                const double e0[3] = {g[k].pos[0] + (long_x ? -(a - rho) : sgn * (a - rho)), g[k].pos[1] + (long_x ? sgn * (b - rho) : -(b - rho)), g[k].pos[2] - c + rho};
+                const double e1[3] = {g[k].pos[0] + (long_x ? (a - rho) : sgn * (a - rho)), g[k].pos[1] + (long_x ? sgn * (b - rho) : (b - rho)), g[k].pos[2] - c + rho};
+                add_seg(P.body, e0, e1, rho);
+            }
         } else { // capsule
             double r = g[k].size[0];
             double d[3] = {g[k].pos2[0] - g[k].pos[0], g[k].pos2[1] - g[k].pos[1], g[k].pos2[2] - g[k].pos[2]};
@@ -644,6 +743,9 @@ inline void build_mass_and_collision(DynModel &M, const GeomIn *g, int ng) {
                 for (int q = 0; q < 3; ++q) M.col_pos[M.ncol][q] = e ? g[k].pos2[q] : g[k].pos[q];
                 M.col_r[M.ncol] = (float)r; M.ncol++;
             }
+            // the shaft between the two end spheres; a capsule whose shaft is about as short as its diameter (the humanoid's clavicles) is covered by them
+            const double e0[3] = {g[k].pos[0], g[k].pos[1], g[k].pos[2]}, e1[3] = {g[k].pos2[0], g[k].pos2[1], g[k].pos2[2]};
+            if (L > 2.0 * r + 0.02) add_seg(P.body, e0, e1, r);
         }
         m[P.body] += P.mass;
         for (int q = 0; q < 3; ++q) mc[P.body][q] += P.mass * P.c[q];
@@ -695,7 +797,17 @@ inline void fill_dyn_model(DynModel &M, const ParcCharModel &cm, const ParcDynam
     M.dt = dp.sim_dt / (float)sub;
     M.gravity_z = dp.gravity_z;
     // contact compliance (re-authored solver; PhysX's rigid contact has no such parameters)
-    M.kn = 5.0e4f; M.dn = 5.0e2f; M.dtang = 1.0e4f; M.mu = dp.friction;
+    // Friction is a regularised Coulomb law, integrated implicitly (contact_apply: the tangential term dt * beta enters the articulated
+    // inertia, so the damper itself is unconditionally stable): f_t = -beta v_t with beta = dtang while beta |v_t| <= mu f_n (STICK: the
+    // implicit solve then drives the point's tangential velocity to load / beta), else beta = mu f_n / |v_t| (SLIP, the secant of the
+    // cone).  dtang = 3e4 N s/m per point: a planted foot (4 sole corners, 20 kg on it) under a lateral load of half that weight creeps
+    // at 0.8 mm/s (round 2, dtang = 1e4: 2.5 mm/s); the stick regime ends at |v_t| = mu f_n / dtang ~ 2 mm/s.  The value is bounded by
+    // fp32: dt * dtang is a point mass of 250 kg riding on links of ~1 kg, and the joint eliminations (IA - U D^-1 U^T) cancel to what is
+    // left; at dtang = 1e5 a shin + foot jammed between two walls (both contacts saturated) loses positive definiteness and the state
+    // explodes within one control step (found at 16 384 envs, tests/test_dynamics_cpu.py keeps the state), 7e4 still survives that state.
+    // An anchored stick spring (PhysX-style patch friction) would need per-contact state across substeps, which this kernel does not keep.
+    M.kn = 5.0e4f; M.dn = 5.0e2f; M.dtang = 3.0e4f; M.mu = dp.friction;
+    M.ext_acc[0] = 0.f; M.ext_acc[1] = 0.f;
     // PhysX bounds the speed at which a penetration is pushed out (max_depenetration_velocity, ig_env.py:150-160 /
     // dm_env_default.yaml sim.physx).  A spring-damper contact pushes out at v = kn pen / dn once spring and damper balance,
     // so the same bound is a cap on the penetration the spring sees: pen_cap = v_max dn / kn (0.1 m for 10 m/s).

@@ -34,6 +34,8 @@ struct CoopTables {
     int nchild[DYN_MAXB];              // chains attached to a body (other than the continuation of its own chain)
     int child[DYN_MAXB][4];
     float brad[DYN_MAXB];              // bounding radius of the body's collision spheres about the body origin
+    int nsg[DYN_MAXB];                 // collision segments per body (a contiguous range of the model's list; their ends are collision points)
+    int sg0[DYN_MAXB];
 };
 
 // host: split the tree into chains of at most `cap` bodies, leaves first (humanoid: [0,1,2],[3,4,5],[6,7,8],[9,10,11],[12,13,14])
@@ -101,6 +103,12 @@ inline bool build_coop_tables(const DynModel &M, CoopTables &C) {
         C.npt[b]++;
         const float rr = sqrtf(M.col_pos[k][0] * M.col_pos[k][0] + M.col_pos[k][1] * M.col_pos[k][1] + M.col_pos[k][2] * M.col_pos[k][2]);
         if (rr + M.col_r[k] > C.brad[b]) C.brad[b] = rr + M.col_r[k];
+    }
+    for (int k = 0; k < M.nseg; ++k) {
+        const int b = M.seg_body[k];
+        if (C.nsg[b] == 0) C.sg0[b] = k;
+        if (k != C.sg0[b] + C.nsg[b]) return false; // segments of a body must be contiguous
+        C.nsg[b]++;
     }
     return true;
 }
@@ -308,11 +316,8 @@ __global__ __launch_bounds__(64, 1) void k_dynamics_coop(const DynModel *__restr
                             if (C.brad[b] < cell_min && bx >= 2 && bx < DYN_PATCH - 2 && by >= 2 && by < DYN_PATCH - 2 &&
                                 r.z + rootp.z + eo2 - C.brad[b] > s_pmax[el][(bx - 2) * (DYN_PATCH - 4) + by - 2]) npt_b = 0;
                         }
-                        for (int pi = 0; pi < npt_b; ++pi) {
-                            const int kp = C.pt0[b] + pi;
-                            const v3 x = r + mulv(R, mk(M.col_pos[kp][0], M.col_pos[kp][1], M.col_pos[kp][2]));
-                            const v3 g = mk(x.x + rootp.x + eo0, x.y + rootp.y + eo1, x.z + rootp.z + eo2);
-                            const float rad = M.col_r[kp];
+                        // one collision sphere (centre x relative to O, g in global coordinates) against its own column and the higher neighbours
+                        auto sphere_contacts = [&](v3 x, v3 g, float rad, float w) {
                             const int ix = cell_of(g.x, T.min_x, T.dx), iy = cell_of(g.y, T.min_y, T.dy);
                             const int pa_ = ix - s_pox[el], pb_ = iy - s_poy[el];
                             const bool inp = pa_ >= 1 && pa_ < DYN_PATCH - 1 && pb_ >= 1 && pb_ < DYN_PATCH - 1;
@@ -330,8 +335,27 @@ __global__ __launch_bounds__(64, 1) void k_dynamics_coop(const DynModel *__restr
                                                             return inp ? s_patch[el][(pa_ + ox) * DYN_PATCH + pb_ + oy] : hf_at(T, ix + ox, iy + oy); }, n)
                                                       : sphere_vs_column(T, g, rad, ix + ox_, iy + oy_, top, n);
                                 if (!(pen > 0.f)) continue;
-                                contact_apply(Mg, dt, x, vpt, pen, n, IA, pA, fsum);
+                                contact_apply(Mg, dt, x, vpt, pen, n, IA, pA, fsum, w);
                             }
+                        };
+                        const v3 goff = mk(rootp.x + eo0, rootp.y + eo1, rootp.z + eo2);
+                        for (int pi = 0; pi < npt_b; ++pi) {
+                            const int kp = C.pt0[b] + pi;
+                            const v3 x = r + mulv(R, mk(M.col_pos[kp][0], M.col_pos[kp][1], M.col_pos[kp][2]));
+                            sphere_contacts(x, x + goff, M.col_r[kp], 1.f);
+                        }
+                        // shafts of capsules / sole edges against the columns' top edges (segment_edge_point); the segments' ends are
+                        // collision points, so the body-level cull above covers them
+                        const int nsg_b = npt_b > 0 ? C.nsg[b] : 0;
+                        for (int si = 0; si < nsg_b; ++si) {
+                            const int ks = C.sg0[b] + si;
+                            const v3 xa = r + mulv(R, mk(M.seg_a[ks][0], M.seg_a[ks][1], M.seg_a[ks][2]));
+                            const v3 xb = r + mulv(R, mk(M.seg_b[ks][0], M.seg_b[ks][1], M.seg_b[ks][2]));
+                            v3 Q;
+                            const float wq = segment_edge_point(T, xa + goff, xb + goff, [&](int ix, int iy) {
+                                const int a_ = ix - s_pox[el], b_ = iy - s_poy[el];
+                                return (a_ >= 0 && a_ < DYN_PATCH && b_ >= 0 && b_ < DYN_PATCH) ? s_patch[el][a_ * DYN_PATCH + b_] : hf_at(T, ix, iy); }, Q);
+                            if (wq > 0.f) sphere_contacts(Q - goff, Q, M.seg_r[ks], wq);
                         }
 #pragma unroll
                         for (int q = 0; q < CO_MAXLEN; ++q) if (k == q) fcon[q] = fsum;
@@ -354,7 +378,7 @@ __global__ __launch_bounds__(64, 1) void k_dynamics_coop(const DynModel *__restr
                                 float sd = sget(IA, j, j);
                                 PARC_UNROLL
                                 for (int q = 0; q < j; ++q) sd -= Lm[j][q] * Lm[j][q];
-                                sd = sd > 1e-12f ? sqrtf(sd) : 1e-6f;
+                                sd = sd > 1e-12f ? sqrtf(sd) : 1e3f; // a non-positive pivot is a numerical breakdown: treat the direction as immovable (no acceleration) rather than as massless
                                 Lm[j][j] = sd;
                                 PARC_UNROLL
                                 for (int a = j + 1; a < 6; ++a) {

@@ -54,12 +54,15 @@ struct WvBodyC {
     float inertia[6], pad1[2];
     float bc[3], pad2;
     float kp[3], kd[3], arm[3], eff[3], lo[3], hi[3], act_lo[3], act_hi[3]; // the joint's dofs (hinge: [0])
-    float pad3[8];
+    int nsg, sg0;            // collision segments of the body (capsule axes / sole edges, DynModel::seg_*)
+    float pad3[6];
 };
+static_assert(sizeof(WvBodyC) == 256, "WvBodyC is one 256-byte record");
 
 struct WaveTables {
     WvBodyC c[DYN_MAXB];
     float colp[DYN_MAXC][4];               // collision point: body-frame position, radius
+    float seg[DYN_MAXS][8];                // collision segment: end a, radius, end b, pad (body frame)
     int nlimb;
     int len[1 + WV_MAXLIMB];               // chain 0 = trunk, 1.. = limbs
     int body[1 + WV_MAXLIMB][WV_MAXLEN];
@@ -175,6 +178,11 @@ inline bool build_wave_tables(const DynModel &M, const CoopTables &C, WaveTables
         }
     }
     for (int k = 0; k < M.ncol; ++k) { for (int a = 0; a < 3; ++a) W.colp[k][a] = M.col_pos[k][a]; W.colp[k][3] = M.col_r[k]; }
+    for (int k = 0; k < M.nseg; ++k) { for (int a = 0; a < 3; ++a) { W.seg[k][a] = M.seg_a[k][a]; W.seg[k][4 + a] = M.seg_b[k][a]; } W.seg[k][3] = M.seg_r[k]; }
+    for (int b = 0; b < M.B; ++b) {
+        W.c[b].nsg = C.nsg[b]; W.c[b].sg0 = C.sg0[b];
+        if (C.npt[b] + C.nsg[b] > 32) return false; // one hit bit per candidate
+    }
     if (wv_lds_floats(off) * (int)sizeof(float) > 160 * 1024) return false; // does not fit one CU's LDS: the caller falls back to the chain-parallel kernel
     return true;
 }
@@ -267,25 +275,25 @@ struct WvCtx { // per-lane constants of the control step
 };
 
 // a contact with a general normal: the shared statement of parc_dynamics.hpp
-__device__ __forceinline__ void wv_contact_generic(const DynModel &M, float dt, v3 x, v3 vpt, float pen, v3 n, sym6 &IA, s6 &pA, v3 &fsum) {
-    contact_apply(M, dt, x, vpt, pen, n, IA, pA, fsum);
+__device__ __forceinline__ void wv_contact_generic(const DynModel &M, float dt, v3 x, v3 vpt, float pen, v3 n, sym6 &IA, s6 &pA, v3 &fsum, float w) {
+    contact_apply(M, dt, x, vpt, pen, n, IA, pA, fsum, w);
 }
 
 // contact_apply specialised for the normal +z (the sphere's own column, unless it leaves a wall sideways): the rank-1 term
 // then has three non-zero components, w = (x.y, -x.x, 0, 0, 0, 1): 6 entries of IA instead of 21.
-__device__ __forceinline__ void wv_contact_own(const DynModel &M, float dt, v3 x, v3 vpt, float pen, sym6 &IA, s6 &pA, v3 &fsum) {
+__device__ __forceinline__ void wv_contact_own(const DynModel &M, float dt, v3 x, v3 vpt, float pen, sym6 &IA, s6 &pA, v3 &fsum, float w) {
     const bool capped = pen > M.pen_cap;
     if (capped) pen = M.pen_cap;
-    float fn = M.kn * pen - M.dn * vpt.z;
+    float fn = w * (M.kn * pen - M.dn * vpt.z);
     if (fn < 0.f) fn = 0.f;
     const float vtm = DYN_SQRT(vpt.x * vpt.x + vpt.y * vpt.y);
-    float beta = M.dtang;
+    float beta = w * M.dtang;
     if (beta * vtm > M.mu * fn) beta = vtm > 1e-9f ? M.mu * fn * DYN_RCP(vtm) : 0.f;
     const v3 f = mk(-beta * vpt.x, -beta * vpt.y, fn);
     const v3 no = cross(x, f);
     pA.a[0] -= no.x; pA.a[1] -= no.y; pA.a[2] -= no.z; pA.a[3] -= f.x; pA.a[4] -= f.y; pA.a[5] -= f.z;
     fsum = fsum + f;
-    const float bn = fn > 0.f ? (M.dn + (capped ? 0.f : dt * M.kn)) : 0.f;
+    const float bn = fn > 0.f ? w * (M.dn + (capped ? 0.f : dt * M.kn)) : 0.f;
     add_inertia(IA, dt * beta, x, nullptr);
     const float k = dt * (bn - beta);
     IA.s[sidx(0, 0)] += k * x.y * x.y; IA.s[sidx(0, 1)] -= k * x.y * x.x; IA.s[sidx(0, 5)] += k * x.y;
@@ -353,10 +361,30 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
     //          sphere_vs_column / the penetration sign, so the result equals the exhaustive 9-column test of
     //          parc_dynamics.hpp.
     // Lanes with a point outside the staged patch (or a sphere wider than a cell) take the exhaustive path below.
-    const int npt = W.c[b].npt, pt0 = W.c[b].pt0;
+    const int npt = W.c[b].npt, pt0 = W.c[b].pt0, nsg = W.c[b].nsg, sg0 = W.c[b].sg0;
     const float hx = 0.5f * Tp.dx, hy = 0.5f * Tp.dy;
     unsigned hit = 0u;
     bool slow = false;
+    // edge candidate of segment ks (patch frame).  FAST: heights from the staged patch with clamped indices -- both ends of a segment are
+    // collision points of the body, so a lane whose segment leaves the inner patch is a `slow` lane below, which uses the other variant
+    // (global memory outside the patch)
+    auto seg_ends = [&](int ks, v3 &A, v3 &Bv) __attribute__((always_inline)) {
+        A = r + mulv(R, mk(W.seg[ks][0], W.seg[ks][1], W.seg[ks][2])) + rootp;
+        Bv = r + mulv(R, mk(W.seg[ks][4], W.seg[ks][5], W.seg[ks][6])) + rootp;
+    };
+    auto seg_point = [&](int ks, v3 &Q) __attribute__((always_inline)) {
+        v3 A, Bv;
+        seg_ends(ks, A, Bv);
+        return segment_edge_point(Tp, A, Bv, [&](int ix, int iy) {
+            const int a_ = ix < 0 ? 0 : (ix > DYN_PATCH - 1 ? DYN_PATCH - 1 : ix), b_ = iy < 0 ? 0 : (iy > DYN_PATCH - 1 ? DYN_PATCH - 1 : iy);
+            return X.s_patch[(a_ * DYN_PATCH + b_) * 64]; }, Q);
+    };
+    auto seg_point_slow = [&](int ks, v3 &Q) __attribute__((always_inline)) {
+        v3 A, Bv;
+        seg_ends(ks, A, Bv);
+        return segment_edge_point(Tp, A, Bv, [&](int ix, int iy) {
+            return (ix >= 0 && ix < DYN_PATCH && iy >= 0 && iy < DYN_PATCH) ? X.s_patch[(ix * DYN_PATCH + iy) * 64] : hf_at(T, X.pox + ix, X.poy + iy); }, Q);
+    };
     if (__any(hmax > -1.0e38f)) {
         // two points per iteration; the table entries of the NEXT pair are requested at the top of the iteration (they sit in
         // SGPRs by the time they are used) and both look-ups of this pair are in flight together: one exposed wait per pair
@@ -408,53 +436,76 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
     }
 #endif
     if (slow) hit = 0u;
+    // narrow phase of one candidate sphere (centre x relative to O, g = x + rootp in the patch frame) of a lane whose spheres all lie in
+    // the inner patch: own column, then the neighbour columns on the sides whose face is closer than the radius
+    auto narrow = [&](v3 x, v3 g, float rad, float w) __attribute__((always_inline)) {
+        const float zlo = g.z - rad;
+        const int pa_ = cell_of(g.x, Tp.min_x, Tp.dx), pb_ = cell_of(g.y, Tp.min_y, Tp.dy); // patch indices = cell indices of the patch frame
+        const float top0 = X.s_patch[(pa_ * DYN_PATCH + pb_) * 64];
+        const v3 vpt = s6lin(B.vel) + cross(s6ang(B.vel), x);
+        const float pen0 = rad + top0 - g.z;
+        if (g.z >= top0) { // centre above the surface: normal +z
+            if (pen0 > 0.f) wv_contact_own(M, dt, x, vpt, pen0, IA, pA, fsum, w);
+        } else {           // centre inside the solid: cheapest way out (own_column_contact), usually still +z
+            v3 n;
+            const float pen = own_column_contact(Tp, g, rad, pa_, pb_, top0, [&](int ox, int oy) { return X.s_patch[((pa_ + ox) * DYN_PATCH + pb_ + oy) * 64]; }, n);
+            if (n.z > 0.5f) wv_contact_own(M, dt, x, vpt, pen, IA, pA, fsum, w);
+            else wv_contact_generic(M, dt, x, vpt, pen, n, IA, pA, fsum, w);
+        }
+        const float ex = g.x - (Tp.min_x + (float)pa_ * Tp.dx), ey = g.y - (Tp.min_y + (float)pb_ * Tp.dy);
+        const float lim = rad + 1e-3f; // slack >> the rounding of the cell centres: it only admits candidates
+        // (a point of radius 0 -- a box corner, a sole edge -- cannot touch a neighbour column at all: pen = -distance.  `rad` is
+        // wave-uniform, so the whole neighbour block is a scalar branch for the 16 foot corners)
+        const bool nx = rad > 0.f && hx - fabsf(ex) < lim, ny = rad > 0.f && hy - fabsf(ey) < lim;
+        if (nx || ny) {
+            const int sx = ex >= 0.f ? 1 : -1, sy = ey >= 0.f ? 1 : -1;
+            for (int c = 0; c < 3; ++c) { // x side, y side, diagonal
+                const bool want = c == 0 ? nx : (c == 1 ? ny : (nx && ny));
+                if (!want) continue;
+                const int ox_ = c == 1 ? 0 : sx, oy_ = c == 0 ? 0 : sy;
+                const float top = X.s_patch[((pa_ + ox_) * DYN_PATCH + pb_ + oy_) * 64];
+                if (!(top > top0 + 1e-3f) || zlo > top) continue; // only higher neighbours act as walls / step edges
+                v3 n;
+                const float pen = sphere_vs_column(Tp, g, rad, pa_ + ox_, pb_ + oy_, top, n);
+                if (pen > 0.f) wv_contact_generic(M, dt, x, vpt, pen, n, IA, pA, fsum, w);
+            }
+        }
+    };
     for (int pi = 0; pi < npt; ++pi) {
         const bool mine = (hit >> pi) & 1u;
         if (!__any(mine)) continue; // uniform
         if (mine) {
             const int kp = pt0 + pi;
             const v3 x = r + mulv(R, mk(W.colp[kp][0], W.colp[kp][1], W.colp[kp][2]));
-            const v3 g = x + rootp;
-            const float rad = W.colp[kp][3];
-            const float zlo = g.z - rad;
-            const int pa_ = cell_of(g.x, Tp.min_x, Tp.dx), pb_ = cell_of(g.y, Tp.min_y, Tp.dy); // patch indices = cell indices of the patch frame
-            const float top0 = X.s_patch[(pa_ * DYN_PATCH + pb_) * 64];
-            const v3 vpt = s6lin(B.vel) + cross(s6ang(B.vel), x);
-            const float pen0 = rad + top0 - g.z;
-            if (g.z >= top0) { // centre above the surface: normal +z
-                if (pen0 > 0.f) wv_contact_own(M, dt, x, vpt, pen0, IA, pA, fsum);
-            } else {           // centre inside the solid: cheapest way out (own_column_contact), usually still +z
-                v3 n;
-                const float pen = own_column_contact(Tp, g, rad, pa_, pb_, top0, [&](int ox, int oy) { return X.s_patch[((pa_ + ox) * DYN_PATCH + pb_ + oy) * 64]; }, n);
-                if (n.z > 0.5f) wv_contact_own(M, dt, x, vpt, pen, IA, pA, fsum);
-                else wv_contact_generic(M, dt, x, vpt, pen, n, IA, pA, fsum);
-            }
-            const float ex = g.x - (Tp.min_x + (float)pa_ * Tp.dx), ey = g.y - (Tp.min_y + (float)pb_ * Tp.dy);
-            const float lim = rad + 1e-3f; // slack >> the rounding of the cell centres: it only admits candidates
-            // (a point of radius 0 -- a box corner -- cannot touch a neighbour column at all: pen = -distance.  `rad` is
-            // wave-uniform, so the whole neighbour block is a scalar branch for the 16 foot corners)
-            const bool nx = rad > 0.f && hx - fabsf(ex) < lim, ny = rad > 0.f && hy - fabsf(ey) < lim;
-            if (nx || ny) {
-                const int sx = ex >= 0.f ? 1 : -1, sy = ey >= 0.f ? 1 : -1;
-                for (int c = 0; c < 3; ++c) { // x side, y side, diagonal
-                    const bool want = c == 0 ? nx : (c == 1 ? ny : (nx && ny));
-                    if (!want) continue;
-                    const int ox_ = c == 1 ? 0 : sx, oy_ = c == 0 ? 0 : sy;
-                    const float top = X.s_patch[((pa_ + ox_) * DYN_PATCH + pb_ + oy_) * 64];
-                    if (!(top > top0 + 1e-3f) || zlo > top) continue; // only higher neighbours act as walls / step edges
-                    v3 n;
-                    const float pen = sphere_vs_column(Tp, g, rad, pa_ + ox_, pb_ + oy_, top, n);
-                    if (pen > 0.f) wv_contact_generic(M, dt, x, vpt, pen, n, IA, pA, fsum);
-                }
-            }
+            narrow(x, x + rootp, W.colp[kp][3], 1.f);
         }
     }
-    if (slow) { // exhaustive test of every point, heights from the patch where it covers them, else from global memory
-        for (int pi = 0; pi < npt; ++pi) {
-            const int kp = pt0 + pi;
-            const v3 x = r + mulv(R, mk(W.colp[kp][0], W.colp[kp][1], W.colp[kp][2]));
+    // The body's segments: where a shaft / sole edge crosses a grid line with a step, the closest point to that edge is one more candidate
+    // sphere (segment_edge_point, parc_dynamics.hpp).  No cull pass of its own: at wave level some lane nearly always has a candidate
+    // (measured), so the candidate is formed once and goes straight to the narrow phase, which is exact by itself.
+    if (__any(hmax > -1.0e38f)) {
+        for (int si = 0; si < nsg; ++si) {
+            v3 Q = rootp;
+            const float wq = seg_point(sg0 + si, Q);
+            const bool has = wq > 0.f && !slow && !(Q.z - W.seg[sg0 + si][3] > hmax);
+            if (!__any(has)) continue; // uniform
+            if (has) narrow(Q - rootp, Q, W.seg[sg0 + si][3], wq);
+        }
+    }
+    if (slow) { // exhaustive test of every candidate, heights from the patch where it covers them, else from global memory
+        for (int pi = 0; pi < npt + nsg; ++pi) {
+            v3 x; float rad, wq = 1.f;
+            if (pi < npt) {
+                const int kp = pt0 + pi;
+                x = r + mulv(R, mk(W.colp[kp][0], W.colp[kp][1], W.colp[kp][2]));
+                rad = W.colp[kp][3];
+            } else {
+                v3 Q = rootp;
+                wq = seg_point_slow(sg0 + pi - npt, Q);
+                if (!(wq > 0.f)) continue;
+                x = Q - rootp; rad = W.seg[sg0 + pi - npt][3];
+            }
             const v3 g = x + rootp;
-            const float rad = W.colp[kp][3];
             const float zlo = g.z - rad;
             if (zlo > hmax) continue;
             const int pa_ = cell_of(g.x, Tp.min_x, Tp.dx), pb_ = cell_of(g.y, Tp.min_y, Tp.dy);
@@ -470,7 +521,7 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
                 const float pen = nb == 4 ? own_column_contact(Tp, g, rad, pa_, pb_, top0, [&](int ox, int oy) {
                                                 return inp ? X.s_patch[((pa_ + ox) * DYN_PATCH + pb_ + oy) * 64] : hf_at(T, ix + ox, iy + oy); }, n)
                                           : sphere_vs_column(Tp, g, rad, pa_ + ox_, pb_ + oy_, top, n);
-                if (pen > 0.f) wv_contact_generic(M, dt, x, vpt, pen, n, IA, pA, fsum);
+                if (pen > 0.f) wv_contact_generic(M, dt, x, vpt, pen, n, IA, pA, fsum, wq);
             }
         }
     }
@@ -919,7 +970,7 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
                         float sd = sget(IA, j, j);
                         PARC_UNROLL
                         for (int q = 0; q < j; ++q) sd -= Lm[j][q] * Lm[j][q];
-                        sd = sd > 1e-12f ? DYN_SQRT(sd) : 1e-6f;
+                        sd = sd > 1e-12f ? DYN_SQRT(sd) : 1e3f; // a non-positive pivot is a numerical breakdown: treat the direction as immovable rather than as massless
                         const float isd = DYN_RCP(sd);
                         PARC_UNROLL
                         for (int a = j + 1; a < 6; ++a) {

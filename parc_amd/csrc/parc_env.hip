@@ -1522,6 +1522,21 @@ extern "C" int parc_env_create(const ParcEnvConfig *cfg, ParcEnv **out) {
     if (cfg->enable_dynamics) {
         memset(&e->h_dyn, 0, sizeof(e->h_dyn));
         parcdyn::fill_dyn_model(e->h_dyn, cfg->model, cfg->dynamics, cfg->action_low, cfg->action_high);
+        // developer switches for ablation measurements (tools/kbench.py); the product never sets them
+        if (const char *sv = getenv("PARC_DYN_SEGMENTS")) { // "none": collision points only; "capsules": drop the sole edges of boxes
+            const std::string mode = sv;
+            parcdyn::DynModel &dm = e->h_dyn;
+            int keep = 0;
+            for (int k = 0; k < dm.nseg; ++k) {
+                const bool drop = mode == "none" || (mode == "capsules" && dm.seg_r[k] <= 0.011f);
+                if (drop) continue;
+                dm.seg_body[keep] = dm.seg_body[k]; dm.seg_r[keep] = dm.seg_r[k];
+                for (int a = 0; a < 3; ++a) { dm.seg_a[keep][a] = dm.seg_a[k][a]; dm.seg_b[keep][a] = dm.seg_b[k][a]; }
+                ++keep;
+            }
+            dm.nseg = keep;
+        }
+        if (const char *sv = getenv("PARC_DYN_DTANG")) e->h_dyn.dtang = (float)atof(sv);
         if ((r = up((void **)&e->d_dyn, &e->h_dyn, sizeof(e->h_dyn))) != hipSuccess) {
             free_dev(e); delete e;
             return fail(PARC_ERR_HIP, std::string("device allocation failed: ") + hipGetErrorString(r));

@@ -223,3 +223,198 @@ def test_own_column_exit_rule():
     # just under the top of a pillar: up (3 cm) beats sideways (15 cm)
     pen, nn = q([1.0, 0.0, 0.0, 0.0, 0.0], 0.05, 0.0, 0.97, 0.0)
     assert nn == (0.0, 0.0, 1.0) and abs(pen - 0.03) < 1e-6
+
+
+# ---- edge contacts of shafts and soles (round 3): single rigid bodies built through the same C structs -------------------------
+def _single_body(sc, gtype, pos, pos2, size, density=1000.0):
+    """DynOracle of ONE free rigid body carrying one geom (type 0 box / 2 capsule as in ParcDynamicsParams)."""
+    import copy
+    import ctypes as C
+    from oracle.binding_dyn import DynOracle
+    from parc_amd import lib as L
+    cfg = L.ParcEnvConfig.from_buffer_copy(bytes(sc.cfg))
+    cfg.model.num_bodies = 1; cfg.model.dof_size = 0
+    cfg.model.parent[0] = -1
+    dp = cfg.dynamics
+    dp.num_geoms = 1; dp.geom_body[0] = 0; dp.geom_type[0] = gtype; dp.geom_density[0] = density
+    for a in range(3):
+        dp.geom_pos[0][a] = pos[a]; dp.geom_pos2[0][a] = pos2[a]; dp.geom_size[0][a] = size[a]
+    return DynOracle(cfg)
+
+
+def _rigid_state(n, pos, quat=(0, 0, 0, 1)):
+    st = dict(root_pos=np.tile(np.asarray(pos, np.float32), (n, 1)), root_rot=np.tile(np.asarray(quat, np.float32), (n, 1)),
+              root_vel=np.zeros((n, 3), np.float32), root_ang_vel=np.zeros((n, 3), np.float32), dof_pos=np.zeros((n, 0), np.float32),
+              dof_vel=np.zeros((n, 0), np.float32), contact_force=np.zeros((n, 1, 3), np.float32))
+    return st
+
+
+MINP, DX = (-12.8, -12.8), (0.4, 0.4)
+X_EDGE = -12.8 + 31.5 * 0.4   # -0.2: the grid line between cells 31 and 32
+
+
+def _platform(top=1.0):
+    hf = np.zeros((64, 64), np.float32)
+    hf[32:, :] = top            # platform on x > X_EDGE, pit on x < X_EDGE
+    return hf
+
+
+def test_segment_edge_point_geometry(dyn):
+    d, sc = dyn
+    assert d.num_segments() == 8 + 4           # eight capsule shafts (arms, thighs, shins; not the stubby clavicles) + the two long sole edges of each foot
+    hf = _platform(1.0)
+    # horizontal shaft 3 cm above the lip, crossing it at right angles: the candidate is the point over the lip
+    q = d.segment_edge_point(hf, MINP, DX, [X_EDGE - 0.15, 0.0, 1.03], [X_EDGE + 0.25, 0.0, 1.03])
+    assert q is not None and np.allclose(q[:3], [X_EDGE, 0.0, 1.03], atol=1e-5) and q[3] == 1.0   # 37 % along the segment: full weight
+    # inclined shaft (45 degrees, rising towards the platform) whose axis passes 5 cm above the lip measured vertically:
+    # the closest point to the edge is NOT the crossing of the grid line but the foot of the perpendicular, 5 / sqrt(2) cm away
+    a, b = np.array([X_EDGE - 0.2, 0.1, 0.85]), np.array([X_EDGE + 0.2, 0.1, 1.25])
+    q = d.segment_edge_point(hf, MINP, DX, a, b)
+    assert q is not None and abs(np.hypot(q[0] - X_EDGE, q[2] - 1.0) - 0.05 / np.sqrt(2)) < 1e-5 and abs(q[1] - 0.1) < 1e-6
+    # flat ground on both sides of the line, or a shaft that crosses no line: no candidate
+    assert d.segment_edge_point(np.zeros((64, 64), np.float32), MINP, DX, [X_EDGE - 0.15, 0.0, 0.03], [X_EDGE + 0.25, 0.0, 0.03]) is None
+    assert d.segment_edge_point(hf, MINP, DX, [X_EDGE + 0.05, 0.0, 1.03], [X_EDGE + 0.30, 0.0, 1.03]) is None
+    # towards an end of the segment the candidate fades out (w = 10 min(t, 1 - t)): the end sphere / corner point that sits there takes over
+    q = d.segment_edge_point(hf, MINP, DX, [X_EDGE - 0.01, 0.0, 1.03], [X_EDGE + 0.39, 0.0, 1.03])
+    assert q is not None and abs(q[3] - 0.25) < 1e-3                                            # 2.5 % along: a quarter of the strength
+    assert d.segment_edge_point(hf, MINP, DX, [X_EDGE + 0.001, 0.0, 1.03], [X_EDGE + 0.3, 0.0, 1.5]) is None   # the closest point lies before the end
+    # an edge along x (platform on y > Y_EDGE) is found through the y axis
+    hf2 = np.zeros((64, 64), np.float32); hf2[:, 32:] = 0.6
+    q = d.segment_edge_point(hf2, MINP, DX, [0.3, X_EDGE - 0.1, 0.65], [0.3, X_EDGE + 0.2, 0.65])
+    assert q is not None and np.allclose(q[:3], [0.3, X_EDGE, 0.65], atol=1e-5)
+
+
+def test_shaft_lying_across_a_platform_edge_is_supported(dyn):
+    """A capsule (shin-sized: r = 5 cm, 40 cm long) lies on a platform with 15 cm of its length and one end sphere hanging over the
+    lip; its centre of mass is over the platform, so it must stay.  With the end spheres alone (the round-2 geometry: counterfactual
+    below) only the end on the platform is supported and the shaft rotates through the lip into the pit."""
+    d, sc = dyn
+    cap = _single_body(sc, 2, (-0.2, 0.0, 0.0), (0.2, 0.0, 0.0), (0.05, 0, 0))
+    assert cap.num_segments() == 1
+    hf = _platform(1.0)
+
+    def run(o):
+        st = _rigid_state(1, (X_EDGE + 0.05, 0.0, 1.0 + 0.05 + 0.002))   # axis 5.2 cm above the top: ends at X_EDGE - 0.15 / + 0.25
+        zmin_free_end = 9.9
+        for _ in range(45):   # 1.5 s
+            o.step(hf, MINP, DX, st, np.zeros((1, 0), np.float32), np.zeros((1, 3), np.float32))
+            q = st["root_rot"][0]
+            ex = np.array([1 - 2 * (q[1] ** 2 + q[2] ** 2), 2 * (q[0] * q[1] + q[2] * q[3]), 2 * (q[0] * q[2] - q[1] * q[3])])  # body x axis
+            zmin_free_end = min(zmin_free_end, (st["root_pos"][0] - 0.2 * ex)[2])
+        return st, zmin_free_end
+    st, zfree = run(cap)
+    assert zfree > 1.0 + 0.05 - 0.01, zfree                              # the hanging end never drops below resting height - 1 cm
+    assert abs(st["root_pos"][0, 2] - 1.05) < 0.01 and np.abs(st["root_vel"]).max() < 0.02
+    assert abs(st["contact_force"][0, 0, 2] - 9.81 * cap.mass_properties()[3]) < 0.05 * 9.81 * cap.mass_properties()[3]
+    cap.set_num_segments(0)
+    _, zfree0 = run(cap)
+    assert zfree0 < 1.0 + 0.05 - 0.04, zfree0                            # counterfactual: without the shaft contact it swings through the lip
+
+
+def test_sole_coming_down_on_a_lip_between_its_corners_is_stopped(dyn):
+    """A foot-sized box pitched 25 degrees (toe up) is dropped so that the middle of its sole meets the lip of a step: toe corners end
+    up above the platform, heel corners over the pit, no corner touches.  The sole edges must be stopped by the lip (penetration of the
+    solid's corner stays at the contact compliance scale); with the corners alone the box sinks in by centimetres."""
+    d, sc = dyn
+    a, b, c = 0.0885, 0.045, 0.0275
+    box = _single_body(sc, 0, (0.0, 0.0, 0.0), (0, 0, 0), (a, b, c), density=1141.0 * 20.0)   # loaded like a foot carrying the body (~20 kg)
+    assert box.num_segments() == 2
+    hf = _platform(1.0)
+    th = np.deg2rad(-25.0)                                                  # rotation about +y by -25 deg lifts the +x end (the toe)
+    quat = (0.0, np.sin(th / 2), 0.0, np.cos(th / 2))
+    Rm = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]])
+
+    def corner_depth(st):
+        """deepest penetration of the two long sole edges into the solid's corner: min(depth below the top, depth behind the face)"""
+        p0 = st["root_pos"][0].astype(np.float64); q = st["root_rot"][0].astype(np.float64)
+        x, y, z, w = q
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        worst = 0.0
+        for sy in (-b, b):
+            for t in np.linspace(-a, a, 41):
+                p = p0 + R @ np.array([t, sy, -c])
+                if p[0] > X_EDGE and p[2] < 1.0:
+                    worst = max(worst, min(1.0 - p[2], p[0] - X_EDGE))
+        return worst
+
+    def run(o):
+        mid_sole = Rm @ np.array([0.0, 0.0, -c])                           # sole centre relative to the box centre
+        st = _rigid_state(1, (X_EDGE - mid_sole[0], 0.0, 1.0 - mid_sole[2] + 0.01), quat)   # sole centre 1 cm above the lip
+        worst = 0.0
+        for _ in range(8):                                                 # ~0.27 s: the touch-down
+            o.step(hf, MINP, DX, st, np.zeros((1, 0), np.float32), np.zeros((1, 3), np.float32))
+            worst = max(worst, corner_depth(st))
+        return worst
+    w1 = run(box)
+    box.set_num_segments(0)
+    w0 = run(box)
+    assert w1 < 0.012, w1            # stopped at the contact compliance scale
+    assert w0 > 0.03 and w0 > 3.0 * w1, (w0, w1)   # counterfactual: corners only -> the lip cuts centimetres into the sole
+
+
+def test_planted_foot_sticks_under_a_lateral_load_and_slides_beyond_the_cone(dyn):
+    """Friction (regularised Coulomb, implicit): a foot-sized box carrying 20 kg rests on flat ground; gravity is tilted so that the
+    lateral load is 0.5 of the weight (mu = 1: inside the cone) -- it must not creep (< 1 mm/s; the round-2 'capped viscous' setting,
+    dtang = 1e4, creeps at 2.5 mm/s: counterfactual; the value is bounded by fp32, see fill_dyn_model); at 1.3 of the weight (outside the cone) it must slide, accelerating at
+    ~ (1.3 - mu) g."""
+    d, sc = dyn
+    a, b, c = 0.0885, 0.045, 0.0275
+    box = _single_body(sc, 0, (0.0, 0.0, 0.0), (0, 0, 0), (a, b, c), density=1141.0 * 20.0)
+    flat = np.zeros((64, 64), np.float32)
+    g = 9.81
+
+    def creep(o, lateral, seconds=1.0):
+        st = _rigid_state(1, (0.03, 0.02, c - 0.002))
+        o.set_ext_acc(0.0, 0.0)
+        for _ in range(15):                       # settle
+            o.step(flat, MINP, DX, st, np.zeros((1, 0), np.float32), np.zeros((1, 3), np.float32))
+        o.set_ext_acc(lateral * g, 0.0)
+        for _ in range(10):                       # load on, let the transient pass
+            o.step(flat, MINP, DX, st, np.zeros((1, 0), np.float32), np.zeros((1, 3), np.float32))
+        x0 = st["root_pos"][0, 0].astype(np.float64)
+        k = int(round(seconds * 30))
+        for _ in range(k):
+            o.step(flat, MINP, DX, st, np.zeros((1, 0), np.float32), np.zeros((1, 3), np.float32))
+        o.set_ext_acc(0.0, 0.0)
+        return (st["root_pos"][0, 0] - x0) / seconds, st
+    v_stick, st = creep(box, 0.5)
+    assert 0.0 <= v_stick < 1.0e-3, v_stick
+    assert abs(st["contact_force"][0, 0, 0] + 0.5 * st["contact_force"][0, 0, 2]) < 0.05 * st["contact_force"][0, 0, 2]   # friction balances the load
+    c0 = box.get_contact()
+    assert c0["dtang"] == 3.0e4 and c0["mu"] == 1.0
+    box.set_contact(c0["kn"], c0["dn"], 1.0e4, c0["mu"])
+    v_old, _ = creep(box, 0.5)
+    assert v_old > 2.0e-3, v_old                  # what round 2 did
+    box.set_contact(c0["kn"], c0["dn"], c0["dtang"], c0["mu"])
+    v_slip, st = creep(box, 1.3, seconds=0.5)
+    # outside the cone: a = (1.3 - mu) g = 2.9 m/s^2; over [t1, t1 + 0.5] with t1 = 1/3 s: mean speed = a (t1 + 0.25)
+    assert 0.6 * 2.9 * (1.0 / 3.0 + 0.25) < v_slip < 1.3 * 2.9 * (1.0 / 3.0 + 0.25), v_slip
+
+
+def test_jammed_leg_state_stays_bounded():
+    """Regression: env 3301 of the 16 384-env cfg-3 settle run (tools/nan_hunt.py, round 3), a shin and a foot jammed between two walls with
+    both contacts saturated.  With the friction stiffness at 1e5 N s/m the fp32 joint eliminations lost positive definiteness and the state
+    went from 1 m/s to 1e11 m/s within one control step; the shipped value (and twice it) must keep it bounded."""
+    import pathlib
+    import tempfile
+    import test_dynamics_gpu as TG
+    from oracle.binding_dyn import DynOracle
+    from parc_amd.envs import scene
+    z = golden("dyn_jammed_leg_state")
+    cfg = TG._cfg3(pathlib.Path(tempfile.mkdtemp()), 1024)
+    sc = scene.build_scene(cfg, 16384, 0, 0, None, seed=21, enable_dynamics=True, verbose=False)
+    e = int(z["env_id"][0])
+    assert np.allclose(sc.env_offsets[e], z["env_offsets"][0])
+    d = DynOracle(sc.cfg)
+    ter = sc.grid.terrain
+    c0 = d.get_contact()
+    for dtang in (c0["dtang"], 2.0 * c0["dtang"]):
+        d.set_contact(c0["kn"], c0["dn"], dtang, c0["mu"])
+        st = dict(root_pos=z["_char_root_pos"].copy(), root_rot=z["_char_root_rot"].copy(), root_vel=z["_char_root_vel"].copy(),
+                  root_ang_vel=z["_char_root_ang_vel"].copy(), dof_pos=z["_char_dof_pos"].copy(), dof_vel=z["_char_dof_vel"].copy(),
+                  contact_force=np.zeros((1, 15, 3), np.float32))
+        for _ in range(10):
+            d.step(ter.hf, ter.min_point, ter.dxdy, st, z["act"], z["env_offsets"])
+            assert np.isfinite(st["root_pos"]).all()
+            assert np.linalg.norm(st["root_vel"]) < 8.0 and np.abs(st["dof_vel"]).max() < 40.0, (dtang, st["root_vel"], np.abs(st["dof_vel"]).max())

@@ -68,26 +68,31 @@ def test_dynamics_at_bench_sizes(tmp_path, n, motions):
     assert z.min() > hf.min() - 1.0 and z.max() < hf.max() + 4.0
     rq = to_np(env._char_root_rot)
     assert np.abs(np.linalg.norm(rq, axis=1) - 1.0).max() < 1e-4
-    # (2) settle: hold the reset pose with zero velocity for 4 s, no resets.  Whatever a character ends up doing (standing,
-    # kneeling, lying at the foot of a wall), at rest its contact forces carry its weight and its kinetic energy is gone.
-    # (A few percent are still on their way down the 12 m pits of the TEASER terrain.)
+    # (2) settle: hold the reset pose with zero velocity for 8 s, no resets.  Whatever a character ends up doing (standing, kneeling,
+    # lying at the foot of a wall), at rest its contact forces carry its weight and its kinetic energy is gone.  Coming to rest takes
+    # long for a held-pose mannequin on this terrain: it balances, topples (the median env needs 2 s), and a few percent then tumble down
+    # the ledges of pits up to 13.6 m deep.  tools/dyn_settle_diag.py classifies the envs outside +-25 %: at 4 s they
+    # are still moving (falling, tumbling with one or two contacts), at 8 s 0.8 % are left (round 3: 0.935 / 0.992; round 2: 0.930 / 0.982).
     env.reset()
     env._char_root_vel.zero_(); env._char_root_ang_vel.zero_(); env._char_dof_vel.zero_()
     hold = env._char_dof_pos.clone()
     speed = []
-    for it in range(120):
+    mg = 9.81 * 50.05  # humanoid.xml: 50.05 kg (DESIGN.md section 4b)
+    within = {}
+    for it in range(240):
         env.step(hold)
         speed.append(float(env._char_root_vel.norm(dim=-1).median()))
+        if it in (119, 239):
+            within[it] = float(np.mean(np.abs(to_np(env._char_contact_forces)[:, :, 2].sum(1) / mg - 1.0) < 0.25))
     _finite_state(env)
-    mg = 9.81 * 50.05  # humanoid.xml: 50.05 kg (DESIGN.md section 4b)
     fz = to_np(env._char_contact_forces)[:, :, 2].sum(1) / mg
     assert 0.97 < np.median(fz) < 1.03, np.median(fz)
-    assert np.mean(np.abs(fz - 1.0) < 0.25) > 0.85, np.mean(np.abs(fz - 1.0) < 0.25)   # measured 0.93 (tools/dyn_settle_diag.py)
+    assert within[119] > 0.90 and within[239] > 0.98, within
     fxy = np.abs(to_np(env._char_contact_forces)[:, :, :2].sum(1)) / mg
     assert np.median(fxy) < 0.25, np.median(fxy)                                  # friction cone: |F_t| <= mu F_n with mu = 1
     assert speed[-1] < 0.05 and speed[-1] < 0.1 * max(speed), (speed[-1], max(speed))  # kinetic energy is gone
     sp = to_np(env._char_root_vel.norm(dim=-1))
-    assert np.quantile(sp, 0.99) < 16.0 and sp.max() < 30.0, (np.quantile(sp, 0.99), sp.max())   # nobody is launched; 16 m/s = a 12 m fall
+    assert np.quantile(sp, 0.99) < 1.0 and sp.max() < 30.0, (np.quantile(sp, 0.99), sp.max())   # after 8 s 99 % are at rest (measured q99 0.11 m/s); nobody is launched
     assert np.mean(np.abs(to_np(env._char_contact_forces)).reshape(n, -1).max(1) > 20 * mg) < 5e-3
     assert env._lib.parc_env_dynamics_timeouts(env._handle) == 0   # no flag wait between the waves of a block ever hit its bound
 

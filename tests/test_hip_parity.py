@@ -367,7 +367,7 @@ def test_dynamics_kernel_matches_cpu_build(tmp_path):
     from helpers import CLIPS4
     from oracle.binding_dyn import DynOracle
     from parc_amd.envs.hip_parkour_env import HipParkourEnv
-    n = 512
+    n = 2048
     cfg = default_config()
     cfg["env"]["dm"]["motion_file"] = write_motion_yaml(tmp_path, CLIPS4, [1, 1, 1, 1])
     env = HipParkourEnv(cfg, n, "cuda:0", False, seed=5, enable_dynamics=True)
@@ -376,7 +376,7 @@ def test_dynamics_kernel_matches_cpu_build(tmp_path):
     sc = env._scene
     hf, mp, dxdy = sc.grid.terrain.hf, sc.grid.terrain.min_point, sc.grid.terrain.dxdy
     gen = torch.Generator(device="cuda:0"); gen.manual_seed(12)
-    for it in range(3):
+    for it in range(4):
         act = (env._char_dof_pos + 0.1 * torch.randn(env._char_dof_pos.shape, device="cuda:0", generator=gen)).contiguous()
         st = dict(root_pos=to_np(env._char_root_pos).copy(), root_rot=to_np(env._char_root_rot).copy(),
                   root_vel=to_np(env._char_root_vel).copy(), root_ang_vel=to_np(env._char_root_ang_vel).copy(),
@@ -384,12 +384,21 @@ def test_dynamics_kernel_matches_cpu_build(tmp_path):
                   contact_force=np.zeros((n, 15, 3), np.float32))
         env.step(act)
         d.step(hf, mp, dxdy, st, to_np(act), sc.env_offsets)
+        # Evidence-based allowance (tools/dyn_cpu_gpu_diag.py, round 3, MI355X, 2 048 envs x 4 steps): NO env beyond 20 x tol, worst env
+        # 7 x tol (dof_vel, step 4), 99.9 % quantile <= 0.15 tol.  An env may exceed 20 x tol only if the two builds disagree about WHICH
+        # bodies are in contact (a point within rounding of a surface / cell face picked the other branch) -- checked, not assumed --
+        # and even then its root stays within 1 cm; at most 0.2 % of the envs (2 x nothing, rounded up to a handful).
+        cg = np.linalg.norm(to_np(env._char_contact_forces), axis=-1) > 1e-5
+        cc = np.linalg.norm(st["contact_force"], axis=-1) > 1e-5
+        set_differs = (cg != cc).any(1)
         for k_o, k_e, tol in [("root_pos", "_char_root_pos", 2e-4), ("root_rot", "_char_root_rot", 2e-4), ("root_vel", "_char_root_vel", 5e-3),
                               ("root_ang_vel", "_char_root_ang_vel", 2e-2), ("dof_pos", "_char_dof_pos", 1e-3), ("dof_vel", "_char_dof_vel", 5e-2)]:
             err = np.abs(to_np(getattr(env, k_e)) - st[k_o]).reshape(n, -1).max(1)
-            # per env; single envs sit within rounding of a contact switch (a surface, a cell face, the way out of a wall):
-            # there the two builds may pick different branches, everywhere else they agree to rounding
-            assert np.quantile(err, 0.99) <= tol and np.mean(err > 20 * tol) < 0.01, (it, k_o, err.max(), np.quantile(err, 0.99))
+            out = err > 20 * tol
+            assert np.quantile(err[~out], 0.999) <= tol, (it, k_o, np.quantile(err[~out], 0.999))
+            assert out.mean() <= 2e-3 and set_differs[out].all(), (it, k_o, out.sum(), err[out], set_differs[out])
+            if k_o == "root_pos":
+                assert err.max() < 1e-2, (it, err.max())
         fz_g = to_np(env._char_contact_forces)[:, :, 2].sum(1); fz_c = st["contact_force"][:, :, 2].sum(1)
         assert np.quantile(np.abs(fz_g - fz_c), 0.99) < 0.02 * 500.0
         assert torch.isfinite(env._obs_buf).all() and torch.isfinite(env._reward_buf).all()

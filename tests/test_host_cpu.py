@@ -283,3 +283,33 @@ def test_quat_to_exp_map_host_helper_matches_reference_rows():
     from parc_amd.envs.hip_parkour_env import _quat_to_exp_map_np
     g = golden("quat_ops")
     np.testing.assert_allclose(_quat_to_exp_map_np(g["a"]), g["quat_to_exp_map"], atol=2e-6, rtol=0)
+
+
+def test_dynamics_kernel_of_the_built_library_uses_no_scratch(tmp_path):
+    """k_dynamics_wave keeps every body of a chain in registers: that needs its body loops fully unrolled (build flag
+    -pragma-unroll-threshold, __graft_entry__.py) -- with the loops rolled the per-body arrays turn into ~1 KB of scratch per lane and the
+    kernel is several times slower, silently.  Read from the code object of the library as built: private segment 0, 1 wave per SIMD."""
+    import re
+    import shutil
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not (os.path.exists(objdump) and os.path.exists(readelf)):
+        pytest.skip("LLVM binutils of ROCm not present")
+    so = tmp_path / "lib.so"
+    shutil.copy(L.LIB_PATH, so)
+    subprocess.check_call([objdump, "--offloading", str(so)], cwd=str(tmp_path), stdout=subprocess.DEVNULL)
+    co = [f for f in os.listdir(tmp_path) if "gfx950" in f]
+    assert len(co) == 1, os.listdir(tmp_path)
+    notes = subprocess.check_output([readelf, "--notes", str(tmp_path / co[0])], text=True)
+    kern = {}
+    for blk in notes.split("- .agpr_count:")[1:]:     # one metadata block per kernel
+        m = re.search(r"\.name:\s+(\S+)", blk)
+        if m:
+            kern[m.group(1)] = {k: int(v) for k, v in re.findall(r"\.(private_segment_fixed_size|vgpr_count|sgpr_count|group_segment_fixed_size):\s+(\d+)", blk)}
+    wave = [v for k, v in kern.items() if "k_dynamics_wave" in k]
+    assert len(wave) == 1, list(kern)
+    assert wave[0]["private_segment_fixed_size"] == 0, wave[0]
+    assert wave[0]["vgpr_count"] > 256, wave[0]        # VGPRs + AGPRs of the one resident wave per SIMD
+    post = [v for k, v in kern.items() if "k_env_post" in k]
+    assert len(post) == 4 and all(p["vgpr_count"] <= 102 for p in post), post   # 5 waves per SIMD need <= 102 registers

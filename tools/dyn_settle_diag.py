@@ -33,10 +33,13 @@ def ground_under(pos_local):
 
 
 last = []
-for it in range(120):
+hist_f = []
+T_END = int(os.environ.get("SETTLE_STEPS", "120"))
+for it in range(T_END):
     env.step(hold)
-    if it >= 110:
+    if it >= T_END - 10:
         last.append(to_np(env._char_contact_forces)[:, :, 2].sum(1) / mg)
+        hist_f.append(to_np(env._char_contact_forces).copy())
     if it % 15 == 14:
         f = to_np(env._char_contact_forces)
         fz = f[:, :, 2].sum(1) / mg
@@ -79,6 +82,18 @@ for c in sorted(set(cls[out]), key=lambda c: -(cls == c).sum()):
 inside = ~out
 print("inside: fz med %.3f std10 med %.3f speed med %.3f ncont med %.1f" % (np.median(fz[inside]), np.median(std10[inside]), np.median(sp[inside]), np.median(ncont[inside])))
 print("clips:", [c.name for c in sc.clips[:5]], "envs per clip", [int((mid == k).sum()) for k in range(5)])
+names = sc.char_model.get_body_names()
+chat = np.nonzero(out & (std10 > 0.3) & (sp < 1.0))[0]
+print("\nforce chatter detail (last 6 control steps, bodies in contact; forces in units of mg): %d envs" % len(chat))
+hist_f = np.stack(hist_f) / mg            # [10, n, 15, 3]
+touched = (np.linalg.norm(hist_f[:, chat], axis=-1) > 1e-5 / mg).any(0).sum(0)
+print("bodies touching in the chatter envs:", {names[b]: int(touched[b]) for b in range(15) if touched[b]})
+for e in chat[:8]:
+    print(" env", int(e), "clip", int(mid[e]), "speed %.2f" % sp[e], "root z-z0 %.2f" % (to_np(env._char_root_pos)[e, 2] - z0[e]))
+    for k in range(4, 10):
+        fb = hist_f[k, e]
+        act = np.nonzero(np.linalg.norm(fb, axis=-1) > 1e-6)[0]
+        print("   step %d: " % k + "  ".join("%s(%.2f %.2f %.2f)" % (names[b][:10], fb[b, 0], fb[b, 1], fb[b, 2]) for b in act))
 print("timeouts", env.dynamics_timeouts())
 if len(sys.argv) > 2:
     json.dump(dict(n=n, outside=int(out.sum()), rows=rows, inside_fz_med=float(np.median(fz[inside])), inside_std10_med=float(np.median(std10[inside]))),
