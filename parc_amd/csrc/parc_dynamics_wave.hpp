@@ -279,25 +279,28 @@ __device__ __forceinline__ void wv_contact_generic(const DynModel &M, float dt, 
     contact_apply(M, dt, x, vpt, pen, n, IA, pA, fsum, w);
 }
 
-// contact_apply specialised for the normal +z (the sphere's own column, unless it leaves a wall sideways): the rank-1 term
-// then has three non-zero components, w = (x.y, -x.x, 0, 0, 0, 1): 6 entries of IA instead of 21.
-__device__ __forceinline__ void wv_contact_own(const DynModel &M, float dt, v3 x, v3 vpt, float pen, sym6 &IA, s6 &pA, v3 &fsum, float w) {
-    const bool capped = pen > M.pen_cap;
-    if (capped) pen = M.pen_cap;
-    float fn = w * (M.kn * pen - M.dn * vpt.z);
-    if (fn < 0.f) fn = 0.f;
-    const float vtm = DYN_SQRT(vpt.x * vpt.x + vpt.y * vpt.y);
-    float beta = w * M.dtang;
-    if (beta * vtm > M.mu * fn) beta = vtm > 1e-9f ? M.mu * fn * DYN_RCP(vtm) : 0.f;
-    const v3 f = mk(-beta * vpt.x, -beta * vpt.y, fn);
-    const v3 no = cross(x, f);
-    pA.a[0] -= no.x; pA.a[1] -= no.y; pA.a[2] -= no.z; pA.a[3] -= f.x; pA.a[4] -= f.y; pA.a[5] -= f.z;
-    fsum = fsum + f;
-    const float bn = fn > 0.f ? w * (M.dn + (capped ? 0.f : dt * M.kn)) : 0.f;
-    add_inertia(IA, dt * beta, x, nullptr);
-    const float k = dt * (bn - beta);
-    IA.s[sidx(0, 0)] += k * x.y * x.y; IA.s[sidx(0, 1)] -= k * x.y * x.x; IA.s[sidx(0, 5)] += k * x.y;
-    IA.s[sidx(1, 1)] += k * x.x * x.x; IA.s[sidx(1, 5)] -= k * x.x; IA.s[sidx(5, 5)] += k;
+// Contacts at the point x (relative to O), summed in point space: force F and the symmetric 3x3 Bm (xx yy zz xy xz yz) of the implicit
+// term.  pA -= [x x F; F];  IA += dt X^T Bm X with X = [-[x]x 1] (point acceleration = a_lin + alpha x x), i.e. the blocks
+// [[-[x]x Bm [x]x, [x]x Bm], [., Bm]].  For Bm = beta 1 + (bn - beta) n n^T this is contact_apply's add_inertia + symrank1.
+__device__ __forceinline__ void wv_point_apply(float dt, v3 x, v3 F, const float Bm_[6], sym6 &IA, s6 &pA, v3 &fsum) {
+    const v3 no = cross(x, F);
+    pA.a[0] -= no.x; pA.a[1] -= no.y; pA.a[2] -= no.z; pA.a[3] -= F.x; pA.a[4] -= F.y; pA.a[5] -= F.z;
+    fsum = fsum + F;
+    const float bxx = dt * Bm_[0], byy = dt * Bm_[1], bzz = dt * Bm_[2], bxy = dt * Bm_[3], bxz = dt * Bm_[4], byz = dt * Bm_[5];
+    // C = [x]x Bm  (rows: -z B1 + y B2 | z B0 - x B2 | -y B0 + x B1, with Bk the k-th row of Bm)
+    const float c00 = -x.z * bxy + x.y * bxz, c01 = -x.z * byy + x.y * byz, c02 = -x.z * byz + x.y * bzz;
+    const float c10 = x.z * bxx - x.x * bxz, c11 = x.z * bxy - x.x * byz, c12 = x.z * bxz - x.x * bzz;
+    const float c20 = -x.y * bxx + x.x * bxy, c21 = -x.y * bxy + x.x * byy, c22 = -x.y * bxz + x.x * byz;
+    // upper-left block -C [x]x (symmetric): columns of [x]x are (0, z, -y), (-z, 0, x), (y, -x, 0)
+    IA.s[sidx(0, 0)] += c02 * x.y - c01 * x.z; IA.s[sidx(0, 1)] += c00 * x.z - c02 * x.x; IA.s[sidx(0, 2)] += c01 * x.x - c00 * x.y;
+    IA.s[sidx(1, 1)] += c10 * x.z - c12 * x.x; IA.s[sidx(1, 2)] += c11 * x.x - c10 * x.y;
+    IA.s[sidx(2, 2)] += c21 * x.x - c20 * x.y;
+    // upper-right block C
+    IA.s[sidx(0, 3)] += c00; IA.s[sidx(0, 4)] += c01; IA.s[sidx(0, 5)] += c02;
+    IA.s[sidx(1, 3)] += c10; IA.s[sidx(1, 4)] += c11; IA.s[sidx(1, 5)] += c12;
+    IA.s[sidx(2, 3)] += c20; IA.s[sidx(2, 4)] += c21; IA.s[sidx(2, 5)] += c22;
+    // lower-right block Bm
+    IA.s[sidx(3, 3)] += bxx; IA.s[sidx(4, 4)] += byy; IA.s[sidx(5, 5)] += bzz; IA.s[sidx(3, 4)] += bxy; IA.s[sidx(3, 5)] += bxz; IA.s[sidx(4, 5)] += byz;
 }
 
 // articulated inertia / bias of body b: own inertia + contacts + (IA, pA) carried in from the chain's child
@@ -435,51 +438,94 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
         }
     }
 #endif
+    WPIN(IA, pA);
+    WSTAMP(4);  // body test + cull pass
     if (slow) hit = 0u;
     // narrow phase of one candidate sphere (centre x relative to O, g = x + rootp in the patch frame) of a lane whose spheres all lie in
-    // the inner patch: own column, then the neighbour columns on the sides whose face is closer than the radius
+    // the inner patch: own column, then the neighbour columns on the sides whose face is closer than the radius.
+    // All contacts of one sphere act at the same point x, so they are first summed in POINT space -- force F and the 3x3 matrix
+    // Bm = sum beta 1 + (bn - beta) n n^T of the implicit term -- and mapped into the body's 6x6 once (wv_point_apply): one application per
+    // candidate instead of one per contact and per branch.  With lane = env a wave executes every branch some lane takes, and at 64 envs
+    // that is all of them (measured: every point of every body reaches this code in every wave), so the saving is in code that always runs.
+    // Mathematically the sum of contact_apply over the contacts (parc_dynamics.hpp); it rounds differently.
     auto narrow = [&](v3 x, v3 g, float rad, float w) __attribute__((always_inline)) {
         const float zlo = g.z - rad;
         const int pa_ = cell_of(g.x, Tp.min_x, Tp.dx), pb_ = cell_of(g.y, Tp.min_y, Tp.dy); // patch indices = cell indices of the patch frame
-        const float top0 = X.s_patch[(pa_ * DYN_PATCH + pb_) * 64];
-        const v3 vpt = s6lin(B.vel) + cross(s6ang(B.vel), x);
-        const float pen0 = rad + top0 - g.z;
-        if (g.z >= top0) { // centre above the surface: normal +z
-            if (pen0 > 0.f) wv_contact_own(M, dt, x, vpt, pen0, IA, pA, fsum, w);
-        } else {           // centre inside the solid: cheapest way out (own_column_contact), usually still +z
-            v3 n;
-            const float pen = own_column_contact(Tp, g, rad, pa_, pb_, top0, [&](int ox, int oy) { return X.s_patch[((pa_ + ox) * DYN_PATCH + pb_ + oy) * 64]; }, n);
-            if (n.z > 0.5f) wv_contact_own(M, dt, x, vpt, pen, IA, pA, fsum, w);
-            else wv_contact_generic(M, dt, x, vpt, pen, n, IA, pA, fsum, w);
-        }
         const float ex = g.x - (Tp.min_x + (float)pa_ * Tp.dx), ey = g.y - (Tp.min_y + (float)pb_ * Tp.dy);
+        const int sx = ex >= 0.f ? 1 : -1, sy = ey >= 0.f ? 1 : -1;
+        // every height this candidate can ask for -- own cell, the four face neighbours, the diagonal on the centre's side -- is requested
+        // up front: six LDS reads in flight together instead of up to eight dependent round trips (one resident wave per SIMD: nothing
+        // else hides them)
+        const float *hp = X.s_patch + (pa_ * DYN_PATCH + pb_) * 64;
+        float top0 = hp[0], hxp = hp[DYN_PATCH * 64], hxm = hp[-DYN_PATCH * 64], hyp = hp[64], hym = hp[-64], hd = hp[(sx * DYN_PATCH + sy) * 64];
+        asm volatile("" : "+v"(top0), "+v"(hxp), "+v"(hxm), "+v"(hyp), "+v"(hym), "+v"(hd));
+        const v3 vpt = s6lin(B.vel) + cross(s6ang(B.vel), x);
+        v3 F = mk(0.f, 0.f, 0.f);
+        float Bm[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; // xx yy zz xy xz yz
+        auto acc = [&](float pen, v3 n) __attribute__((always_inline)) { // contact_apply's force law, accumulated in point space
+            const bool capped = pen > M.pen_cap;
+            if (capped) pen = M.pen_cap;
+            const float vn = dot(vpt, n);
+            float fn = w * (M.kn * pen - M.dn * vn);
+            if (fn < 0.f) fn = 0.f;
+            const v3 vt = vpt - vn * n;
+            const float vtm = DYN_SQRT(dot(vt, vt));
+            float beta = w * M.dtang;
+            if (beta * vtm > M.mu * fn) beta = vtm > 1e-9f ? M.mu * fn * DYN_RCP(vtm) : 0.f;
+            F = F + (fn * n - beta * vt);
+            const float bn = fn > 0.f ? w * (M.dn + (capped ? 0.f : dt * M.kn)) : 0.f;
+            const float k = bn - beta;
+            Bm[0] += beta + k * n.x * n.x; Bm[1] += beta + k * n.y * n.y; Bm[2] += beta + k * n.z * n.z;
+            Bm[3] += k * n.x * n.y; Bm[4] += k * n.x * n.z; Bm[5] += k * n.y * n.z;
+        };
+        bool touched = false;
+        {   // own column: centre above the surface -> normal +z; centre inside the solid -> cheapest way out (own_column_contact)
+            v3 n = mk(0.f, 0.f, 1.f);
+            float pen = rad + top0 - g.z;
+            if (g.z < top0) pen = own_column_contact(Tp, g, rad, pa_, pb_, top0, [&](int ox, int oy) { return ox == 1 ? hxp : (ox == -1 ? hxm : (oy == 1 ? hyp : hym)); }, n);
+            if (pen > 0.f) { acc(pen, n); touched = true; }
+        }
         const float lim = rad + 1e-3f; // slack >> the rounding of the cell centres: it only admits candidates
-        // (a point of radius 0 -- a box corner, a sole edge -- cannot touch a neighbour column at all: pen = -distance.  `rad` is
-        // wave-uniform, so the whole neighbour block is a scalar branch for the 16 foot corners)
+        // (a point of radius 0 -- a box corner -- cannot touch a neighbour column at all: pen = -distance.  `rad` is wave-uniform, so the
+        // whole neighbour block is a scalar branch for the 16 foot corners)
         const bool nx = rad > 0.f && hx - fabsf(ex) < lim, ny = rad > 0.f && hy - fabsf(ey) < lim;
         if (nx || ny) {
-            const int sx = ex >= 0.f ? 1 : -1, sy = ey >= 0.f ? 1 : -1;
             for (int c = 0; c < 3; ++c) { // x side, y side, diagonal
                 const bool want = c == 0 ? nx : (c == 1 ? ny : (nx && ny));
                 if (!want) continue;
                 const int ox_ = c == 1 ? 0 : sx, oy_ = c == 0 ? 0 : sy;
-                const float top = X.s_patch[((pa_ + ox_) * DYN_PATCH + pb_ + oy_) * 64];
+                const float top = c == 0 ? (sx > 0 ? hxp : hxm) : (c == 1 ? (sy > 0 ? hyp : hym) : hd);
                 if (!(top > top0 + 1e-3f) || zlo > top) continue; // only higher neighbours act as walls / step edges
                 v3 n;
                 const float pen = sphere_vs_column(Tp, g, rad, pa_ + ox_, pb_ + oy_, top, n);
-                if (pen > 0.f) wv_contact_generic(M, dt, x, vpt, pen, n, IA, pA, fsum, w);
+                if (pen > 0.f) { acc(pen, n); touched = true; }
             }
         }
+        if (touched) wv_point_apply(dt, x, F, Bm, IA, pA, fsum);
     };
-    for (int pi = 0; pi < npt; ++pi) {
-        const bool mine = (hit >> pi) & 1u;
-        if (!__any(mine)) continue; // uniform
-        if (mine) {
-            const int kp = pt0 + pi;
-            const v3 x = r + mulv(R, mk(W.colp[kp][0], W.colp[kp][1], W.colp[kp][2]));
-            narrow(x, x + rootp, W.colp[kp][3], 1.f);
+    {   // the table entry of the NEXT point is requested while this one is processed (a scalar load waited for at the top of every
+        // iteration is a ~200-cycle stall with one resident wave per SIMD)
+        struct ColPt2 { float x, y, z, r; };
+        auto load_pt2 = [&](int pi) __attribute__((always_inline)) {
+            const int kp = pt0 + (pi < npt ? pi : 0);
+            ColPt2 c; c.x = W.colp[kp][0]; c.y = W.colp[kp][1]; c.z = W.colp[kp][2]; c.r = W.colp[kp][3];
+            return c;
+        };
+        ColPt2 cur = load_pt2(0);
+        for (int pi = 0; pi < npt; ++pi) {
+            const ColPt2 nxt = load_pt2(pi + 1);
+            const bool mine = (hit >> pi) & 1u;
+            if (__any(mine)) { // uniform
+                if (mine) {
+                    const v3 x = r + mulv(R, mk(cur.x, cur.y, cur.z));
+                    narrow(x, x + rootp, cur.r, 1.f);
+                }
+            }
+            cur = nxt;
         }
     }
+    WPIN(IA, pA);
+    WSTAMP(13); // narrow phase of the collision points
     // The body's segments: where a shaft / sole edge crosses a grid line with a step, the closest point to that edge is one more candidate
     // sphere (segment_edge_point, parc_dynamics.hpp).  No cull pass of its own: at wave level some lane nearly always has a candidate
     // (measured), so the candidate is formed once and goes straight to the narrow phase, which is exact by itself.
@@ -527,7 +573,7 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
     }
     B.fcon = fsum;
     WPIN(IA, pA);
-    WSTAMP(13);
+    WSTAMP(6);  // segments (+ the exhaustive path of lanes outside the patch)
 }
 
 // joint elimination of body b: (IA, pA) -> contribution (Ic, pc) to the parent; K and D^-1 u go to LDS (fac + lane, stride 64)

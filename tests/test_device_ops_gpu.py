@@ -282,3 +282,4 @@ def test_large_library_ema_path_equals_the_per_motion_chain(tmp_path, monkeypatc
         fa, fb = envs[0].get_fail_rates().numpy(), envs[1].get_fail_rates().numpy()
         assert np.array_equal(fa, fb), (s, fa, fb)
     assert (fa < 1.0).all() and torch.equal(envs[0]._motion_ids, envs[1]._motion_ids)
+
