@@ -40,6 +40,14 @@ class DynOracle:
         self.lib.orc_dyn_get_mass(self.h, _p(mass), _p(com), _p(inertia), C.byref(total), C.byref(ncol))
         return mass, com, inertia, total.value, ncol.value
 
+    def inflate(self, eps):
+        """Test hook: grow every collision shape by eps (a contact offset)."""
+        self.lib.orc_dyn_inflate(self.h, C.c_float(eps))
+
+    def set_num_substeps(self, n):
+        """Test hook: substeps per control step (1 = the reported contact force is evaluated at the given pose)."""
+        return int(self.lib.orc_dyn_set_nsub(self.h, C.c_int(n)))
+
     def num_segments(self):
         return int(self.lib.orc_dyn_get_nseg(self.h))
 

@@ -52,6 +52,15 @@ float orc_own_column_contact(const float *tops5, float x, float y, float z, floa
     return pen;
 }
 
+// test hook: grow every collision sphere / segment by eps (PhysX's contact_offset: shapes closer than that generate a contact) -- used to
+// ask "which bodies TOUCH the terrain at this pose" without integrating anything
+void orc_dyn_inflate(void *m, float eps) {
+    DynModel *M = (DynModel *)m;
+    for (int k = 0; k < M->ncol; ++k) M->col_r[k] += eps;
+    for (int k = 0; k < M->nseg; ++k) M->seg_r[k] += eps;
+}
+// test hook: substeps per control step (1: the reported contact force is the one evaluated AT the given pose); returns the old value
+int orc_dyn_set_nsub(void *m, int n) { DynModel *M = (DynModel *)m; const int old = M->nsub; M->nsub = n; return old; }
 int orc_dyn_get_nseg(void *m) { return ((DynModel *)m)->nseg; }
 // counterfactual for the tests: drop the collision segments (points only, the round-2 contact geometry); returns the old count
 int orc_dyn_set_nseg(void *m, int n) { DynModel *M = (DynModel *)m; const int old = M->nseg; M->nseg = n; return old; }
