@@ -264,9 +264,16 @@ def torch_path_baseline(env, seconds, st):
                       "observation assembly or reward"}
 
 
-def _profile_json(name):
-    p = os.path.join(REPO, "profiles", name)
-    return json.load(open(p)) if os.path.exists(p) else None
+def _profile_json(suffix, build=None):
+    """Newest profiles/rNN_<suffix>.  With ``build`` = (csrc hash, build flags): only a file collected on exactly that build of the
+    library (tools/profile_summary.py stores both) -- counter figures of another build would silently describe a different kernel."""
+    import glob
+    for p in sorted(glob.glob(os.path.join(REPO, "profiles", "r[0-9][0-9]_" + suffix)), reverse=True):
+        d = json.load(open(p))
+        if build is None or (d.get("csrc_sha16") == build[0] and d.get("build_flags") == build[1]):
+            d["_file"] = os.path.relpath(p, REPO)
+            return d
+    return None
 
 
 def worker(a):
@@ -383,35 +390,43 @@ def worker(a):
     # Counter-derived figures come from the committed rocprofv3 --pmc passes (profiles/, collected on the 65 536-env
     # default configuration in separate runs), NOT from this run; they are attached only to that configuration.
     at_profiled_cfg = n_local == 65536 and a.motions == 0
+    build = (L.csrc_hash(), env._lib.parc_build_flags().decode())
     post_traffic = None
-    pmc = _profile_json("r02_pmc_hbm_traffic.json") or _profile_json("r01_pmc_hbm_traffic.json")
+    pmc = _profile_json("pmc_hbm_traffic.json", build)
     if pmc and at_profiled_cfg:
         k = [q for q in pmc["FETCH_SIZE_KiB_avg_per_dispatch"] if q.startswith("void k_env_post<0")][0]  # the step instantiation
         post_traffic = (2.0 * pmc["FETCH_SIZE_KiB_avg_per_dispatch"][k] + pmc["WRITE_SIZE_KiB_avg_per_dispatch"][k]) * 1024.0
     post_gbs = BYTES_KINEMATIC * n_local / (post_ms * 1e-3) / 1e9
     obs_kernel = {"kernel": "k_env_post<MODE_STEP> (+ k_env_prep when the dynamics kernel did not write the prep records)", "bound": "hbm", "kernel_ms": post_ms, "achieved": post_gbs, "peak": HBM_PEAK_GBS,
                   "unit": "GB/s", "frac": post_gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_env_step": BYTES_KINEMATIC,
-                  "traffic": post_traffic, "traffic_source": "profiles/ (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate run), not measured in this run"}
+                  "traffic": post_traffic,
+                  "traffic_source": ((pmc["_file"] + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes on this build of the library), not measured in this run")
+                                     if post_traffic else "no counter file of this build / configuration under profiles/")}
     if dynamics_on and dyn_ms >= post_ms:
         # dominant kernel = the dynamics: VALU-issue bound (rigid-body recursion in registers), 844 B of HBM per env-step.
         kname = env._lib.parc_env_dynamics_kernel(env._handle).decode()
         hbm_gbs = BYTES_DYN_KERNEL * n_local / (dyn_ms * 1e-3) / 1e9
-        dj = _profile_json("r02_pmc_dynamics.json")
-        valu = traffic = None
+        dj = _profile_json("pmc_dynamics.json", build)   # only counters collected on THIS build (source hash + flags)
+        valu = traffic = lane_util = None
         if dj and dj.get("kernel") == kname and at_profiled_cfg:
             traffic = 2.0 * dj["FETCH_SIZE_KiB"] * 1024.0 + dj["WRITE_SIZE_KiB"] * 1024.0
             valu = dj.get("SQ_INSTS_VALU")  # wave-level VALU instructions per launch
-        roof = {"bound": "valu", "kernel": kname, "kernel_ms": dyn_ms, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+            lane_util = dj.get("derived", {}).get("lane_utilisation_of_valu")
+        roof = {"bound": "valu", "kernel": kname, "kernel_ms": dyn_ms, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s-equivalent of VALU issue slots",
                 "achieved": None, "frac": None, "traffic": traffic,
-                "traffic_source": "profiles/r02_pmc_dynamics.json (separate rocprofv3 --pmc passes), not measured in this run",
-                "definition": "achieved = wave-level VALU instructions per launch (SQ_INSTS_VALU, profiles/) x 128 flop (64 lanes x FMA) / measured kernel time: "
-                              "the share of the fp32 vector issue slots the kernel fills, an upper bound on its useful flops",
+                "traffic_source": (dj["_file"] + " (separate rocprofv3 --pmc passes on this build of the library), not measured in this run") if valu else None,
+                "definition": "VALU ISSUE-SLOT UTILISATION, not useful flops: achieved = wave-level VALU instructions per launch (SQ_INSTS_VALU, profiles/) x 128 "
+                              "(64 lanes x 2) / measured kernel time, against the packed-fp32 vector peak; every VALU instruction counts (moves, compares, selects) "
+                              "and idle lanes count as busy -- `lane_utilisation` and `frac_of_scalar_fp32_issue_rate` put it in proportion",
                 "hbm": {"achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS,
                         "algorithmic_bytes_per_env_step": BYTES_DYN_KERNEL},
                 "obs_kernel": obs_kernel}
         if valu:
             roof["achieved"] = valu * 128.0 / (dyn_ms * 1e-3) / 1e12
             roof["frac"] = roof["achieved"] / VALU_PEAK_TFLOPS
+            roof["lane_utilisation"] = lane_util
+            # a non-packed fp32 VALU instruction occupies its SIMD for 4 cycles: 1024 SIMDs x 2.4 GHz / 4 instructions per second
+            roof["frac_of_scalar_fp32_issue_rate"] = valu / (dyn_ms * 1e-3) / (1024 * 2.4e9 / 4.0)
         else:  # no counter file for this configuration: fall back to the HBM figure the contract asks for
             roof.update({"bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS,
                          "note": "VALU-bound kernel; no SQ counter file for this configuration, HBM fraction reported instead"})

@@ -354,19 +354,17 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
             if (cb.z + rootp.z - brho > hmax) hmax = -3.0e38f; // clears everything: no point survives the test below
         }
     }
-    // Narrow phase in two passes.  A sphere can only touch the column of its own cell and the columns of the neighbours on
-    // the sides whose face is closer than its radius (for rad < half a cell: at most the x-side, the y-side and their
-    // diagonal; the far sides are at least half a cell away).
-    //   pass 1 (straight-line code, two points per iteration so that their table loads and LDS look-ups overlap): ONE
-    //          look-up of the 3x3 running maximum around the sphere's cell decides whether the point can touch anything;
-    //          survivors set a bit;
-    //   pass 2: only points that survived in some lane are evaluated; whether a candidate is a contact stays with
-    //          sphere_vs_column / the penetration sign, so the result equals the exhaustive 9-column test of
-    //          parc_dynamics.hpp.
+    // Narrow phase.  A sphere can only touch the column of its own cell and the columns of the neighbours on the sides whose face is
+    // closer than its radius (for rad < half a cell: at most the x-side, the y-side and their diagonal; the far sides are at least half a
+    // cell away); whether a candidate is a contact stays with sphere_vs_column / the penetration sign, so the result equals the exhaustive
+    // 9-column test of parc_dynamics.hpp.  Per lane a sphere is only culled against the 5x5 maximum of its body (hmax).  Rounds 1-2 ran a
+    // cull pass per point first (a look-up of the 3x3 running maximum around the sphere's cell, a hit bit per point): with lane = env a
+    // wave executes the narrow phase of a point as soon as ONE of its 64 envs needs it, and that was measured to be the case for every
+    // point of every body in every wave (tools/wave_stamps.py, round 3) -- the pass culled nothing at wave level and cost 11 % of the
+    // kernel; without it 0.493 -> 0.478 ms at 65 536 envs.
     // Lanes with a point outside the staged patch (or a sphere wider than a cell) take the exhaustive path below.
     const int npt = W.c[b].npt, pt0 = W.c[b].pt0, nsg = W.c[b].nsg, sg0 = W.c[b].sg0;
     const float hx = 0.5f * Tp.dx, hy = 0.5f * Tp.dy;
-    unsigned hit = 0u;
     bool slow = false;
     // edge candidate of segment ks (patch frame).  FAST: heights from the staged patch with clamped indices -- both ends of a segment are
     // collision points of the body, so a lane whose segment leaves the inner patch is a `slow` lane below, which uses the other variant
@@ -388,59 +386,16 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
         return segment_edge_point(Tp, A, Bv, [&](int ix, int iy) {
             return (ix >= 0 && ix < DYN_PATCH && iy >= 0 && iy < DYN_PATCH) ? X.s_patch[(ix * DYN_PATCH + iy) * 64] : hf_at(T, X.pox + ix, X.poy + iy); }, Q);
     };
-    if (__any(hmax > -1.0e38f)) {
-        // two points per iteration; the table entries of the NEXT pair are requested at the top of the iteration (they sit in
-        // SGPRs by the time they are used) and both look-ups of this pair are in flight together: one exposed wait per pair
-        struct ColPt { float x, y, z, r; };
-        auto load_pt = [&](int pi) __attribute__((always_inline)) {
-            const int kp = pt0 + (pi < npt ? pi : 0);
-            ColPt c; c.x = W.colp[kp][0]; c.y = W.colp[kp][1]; c.z = W.colp[kp][2]; c.r = W.colp[kp][3];
-            return c;
-        };
-        const float fast_r = X.cell_min * 0.5f - 2e-3f;
-        ColPt c0 = load_pt(0), c1 = load_pt(1);
-        for (int pi = 0; pi < npt; pi += 2) {
-            const ColPt n0 = load_pt(pi + 2), n1 = load_pt(pi + 3);
-            float zlo[2]; int addr[2]; bool inp[2];
-            PARC_UNROLL
-            for (int q = 0; q < 2; ++q) {
-                const ColPt &c = q == 0 ? c0 : c1;
-                const v3 g = r + mulv(R, mk(c.x, c.y, c.z)) + rootp;
-                zlo[q] = g.z - c.r;
-                const int pa_ = cell_of(g.x, Tp.min_x, Tp.dx), pb_ = cell_of(g.y, Tp.min_y, Tp.dy);
-                inp[q] = pa_ >= 1 && pa_ < DYN_PATCH - 1 && pb_ >= 1 && pb_ < DYN_PATCH - 1;
-                const int pac = pa_ < 1 ? 1 : (pa_ > DYN_PATCH - 2 ? DYN_PATCH - 2 : pa_), pbc = pb_ < 1 ? 1 : (pb_ > DYN_PATCH - 2 ? DYN_PATCH - 2 : pb_);
-                addr[q] = ((pac - 1) * WV_P3 + pbc - 1) * 64;
-            }
-            float m3a = X.s_pmax3[addr[0]], m3b = X.s_pmax3[addr[1]];
-            asm volatile("" : "+v"(m3a), "+v"(m3b)); // both look-ups are issued unconditionally (clamped addresses), back to back
-            const bool v1 = pi + 1 < npt;
-            const bool fast0 = inp[0] && c0.r < fast_r, fast1 = inp[1] && c1.r < fast_r;
-            const bool low0 = !(zlo[0] > hmax), low1 = v1 && !(zlo[1] > hmax);
-            hit |= ((fast0 && low0 && !(zlo[0] > m3a)) ? 1u : 0u) << pi;
-            hit |= ((fast1 && low1 && !(zlo[1] > m3b)) ? 2u : 0u) << pi;
-            slow = slow || (low0 && !fast0) || (low1 && !fast1);
-            c0 = n0; c1 = n1;
-        }
-    }
-#ifdef PARC_COUNTS
+    // Which lanes take the straight path: the body's 5x5 window is applicable (all its spheres then lie in the inner patch) and every
+    // sphere is narrower than half a cell.  The others take the exhaustive path further down.
     {
-        const unsigned long long m_near = __ballot(hmax > -1.0e38f), m_hit = __ballot(hit != 0u && !slow), m_slow = __ballot(slow);
-        int bits = __popc(slow ? 0u : hit);
-        for (int off = 32; off >= 1; off >>= 1) bits += __shfl_xor(bits, off, 64);
-        int it2 = 0;
-        for (int pi = 0; pi < npt; ++pi) if (__any(!slow && ((hit >> pi) & 1u))) ++it2;
-        if ((threadIdx.x & 63) == 0) {
-            atomicAdd(&g_wave_cnt[b][0], 64ull); atomicAdd(&g_wave_cnt[b][1], (unsigned long long)__popcll(m_near));
-            atomicAdd(&g_wave_cnt[b][2], m_near ? 1ull : 0ull); atomicAdd(&g_wave_cnt[b][3], (unsigned long long)__popcll(m_hit));
-            atomicAdd(&g_wave_cnt[b][4], (unsigned long long)bits); atomicAdd(&g_wave_cnt[b][5], (unsigned long long)__popcll(m_slow));
-            atomicAdd(&g_wave_cnt[b][6], (unsigned long long)it2); atomicAdd(&g_wave_cnt[b][7], 1ull);
-        }
+        const float fast_r = X.cell_min * 0.5f - 2e-3f;
+        bool wide = false;
+        for (int pi = 0; pi < npt; ++pi) wide = wide || !(W.colp[pt0 + pi][3] < fast_r); // uniform
+        slow = (hmax > 1.0e38f) || (wide && hmax > -1.0e38f);
     }
-#endif
     WPIN(IA, pA);
-    WSTAMP(4);  // body test + cull pass
-    if (slow) hit = 0u;
+    WSTAMP(4);  // body test
     // narrow phase of one candidate sphere (centre x relative to O, g = x + rootp in the patch frame) of a lane whose spheres all lie in
     // the inner patch: own column, then the neighbour columns on the sides whose face is closer than the radius.
     // All contacts of one sphere act at the same point x, so they are first summed in POINT space -- force F and the 3x3 matrix
@@ -514,12 +469,11 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
         ColPt2 cur = load_pt2(0);
         for (int pi = 0; pi < npt; ++pi) {
             const ColPt2 nxt = load_pt2(pi + 1);
-            const bool mine = (hit >> pi) & 1u;
+            const v3 x = r + mulv(R, mk(cur.x, cur.y, cur.z));
+            const v3 g = x + rootp;
+            const bool mine = !slow && !(g.z - cur.r > hmax); // the sphere reaches down to the highest column of the body's window
             if (__any(mine)) { // uniform
-                if (mine) {
-                    const v3 x = r + mulv(R, mk(cur.x, cur.y, cur.z));
-                    narrow(x, x + rootp, cur.r, 1.f);
-                }
+                if (mine) narrow(x, g, cur.r, 1.f);
             }
             cur = nxt;
         }

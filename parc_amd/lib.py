@@ -174,6 +174,18 @@ class ParcError(RuntimeError):
     pass
 
 
+def csrc_hash() -> str:
+    """sha256 (first 16 hex digits) over the kernel sources + the C-ABI header: profiles/*.json carry it, so that bench.py attaches
+    counter-derived figures only to the build they were collected on."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(_HERE, "csrc")
+    for f in sorted(os.listdir(csrc)) + [os.path.join("..", "..", "include", "parc_env.h")]:
+        with open(os.path.join(csrc, f), "rb") as fh:
+            h.update(f.encode()); h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def check(rc):
     if rc != 0:
         raise ParcError(f"libparc_env error {rc}: {load().parc_last_error().decode()}")

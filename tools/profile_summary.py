@@ -1,6 +1,9 @@
 """Summaries of a tools/profile_round.sh run -> <out>/summary/*.json|csv (copy the ones to be judged into profiles/)."""
 import collections, csv, glob, json, os, shutil, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from parc_amd import lib as L
 out, tag = sys.argv[1], sys.argv[2]
+BUILD = {"csrc_sha16": L.csrc_hash(), "build_flags": L.load().parc_build_flags().decode()}  # what the counters were collected on
 os.makedirs(out + "/summary", exist_ok=True)
 
 
@@ -20,7 +23,7 @@ if st:
 if os.path.exists(out + "/bench_under_profiler.json"):
     shutil.copy(out + "/bench_under_profiler.json", out + f"/summary/{tag}_bench_under_profiler.json")
 fe, wr = pmc("fetch"), pmc("write")
-json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only), bench.py --steps 20 (default config: dynamics on, 65536 envs). "
+json.dump({**BUILD, "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only), bench.py --steps 20 (default config: dynamics on, 65536 envs). "
                    "Units: KiB per dispatch; gfx950 FETCH_SIZE reports half of a wide coalesced read (MI355X_MICROARCH.md HBM section): consumers double it.",
            "FETCH_SIZE_KiB_avg_per_dispatch": {k: v["FETCH_SIZE"] for k, v in fe.items() if "FETCH_SIZE" in v},
            "WRITE_SIZE_KiB_avg_per_dispatch": {k: v["WRITE_SIZE"] for k, v in wr.items() if "WRITE_SIZE" in v}},
@@ -41,7 +44,7 @@ if sq:
            "note": "rocprofv3 --pmc, four counters per pass, --kernel-trace only, averages per dispatch. SQ_* cycle counters are per-wave quad-cycles summed over "
                    "waves; 4096 waves = 1024 blocks x 4 waves, 1 wave per SIMD.",
            "FETCH_SIZE_KiB": fe.get(dk, {}).get("FETCH_SIZE"), "WRITE_SIZE_KiB": wr.get(dk, {}).get("WRITE_SIZE")}
-    rec.update(sq); rec["derived"] = der
+    rec.update(sq); rec["derived"] = der; rec.update(BUILD)
     json.dump(rec, open(out + f"/summary/{tag}_pmc_dynamics.json", "w"), indent=1)
 c5f, c5w = pmc("c5fetch"), pmc("c5write")
 if c5f:
