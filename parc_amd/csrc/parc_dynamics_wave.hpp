@@ -720,7 +720,9 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
     float *s_attkin = smem + WV_OFF_ATTKIN + lane, *s_up = smem + WV_OFF_UP + lane, *s_attacc = smem + WV_OFF_ATTACC + lane;
     float *s_rootp = smem + WV_OFF_ROOTP + lane, *s_patch = smem + WV_OFF_PATCH + lane, *s_pmax = smem + WV_OFF_PMAX + lane;
     float *s_fac = smem + WV_OFF_FAC + lane, *s_rooti = smem + WV_OFF_ROOTI + lane, *s_pmax3 = smem + WV_OFF_PMAX3 + lane;
-    volatile int *s_flag = reinterpret_cast<volatile int *>(smem + WV_OFF_FLAG);
+    // hand-off flags: workgroup-scope atomics in LDS (release store by the producer after its record, acquire load by the consumer before
+    // it reads the record); [15] = "a wait of this block timed out"
+    int *s_flag = reinterpret_cast<int *>(smem + WV_OFF_FLAG);
     if (threadIdx.x < 16) s_flag[threadIdx.x] = 0; // published before the first barrier below
 
     const float *dp = buf.char_dof_pos + (size_t)D_ * ec, *dv = buf.char_dof_vel + (size_t)D_ * ec, *ac = action + (size_t)D_ * ec;
@@ -824,14 +826,21 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
 #ifdef PARC_TEST_BREAK_FLAG
         if (f == (PARC_TEST_BREAK_FLAG)) return;
 #endif
+        // every lane wrote its env's slot of the record: the wave's LDS stores complete in order, the fence waits for them (one
+        // s_waitcnt for the whole wave), then lane 0 raises the flag
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) s_flag[f] = sub + 1;
+        if (lane == 0) __hip_atomic_store(&s_flag[f], sub + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
     auto await = [&](int f, int sub) __attribute__((always_inline)) {
         int spins = 0;
-        while (s_flag[f] <= sub) { // bounded: a protocol error must not hang the GPU, and must not go unnoticed: the block's envs are
-                                   // poisoned at the end (s_flag[15]) and the device counter is bumped here, in the cold path only
-            if (++spins == PARC_FLAG_SPIN_BOUND) { s_flag[15] = 1; if (lane == 0) atomicAdd(&g_wave_timeouts, 1u); break; }
+        // bounded: a protocol error must not hang the GPU, and must not go unnoticed: the block's envs are poisoned at the end (s_flag[15])
+        // and the device counter is bumped here, in the cold path only
+        while (__hip_atomic_load(&s_flag[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= sub) {
+            if (++spins == PARC_FLAG_SPIN_BOUND) {
+                __hip_atomic_store(&s_flag[15], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (lane == 0) atomicAdd(&g_wave_timeouts, 1u);
+                break;
+            }
             __builtin_amdgcn_s_sleep(2);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -1126,7 +1135,7 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
     // A flag wait of this block hit its bound: some wave integrated a stale record.  Every wave checks as its LAST action (a wave that
     // timed out sees its own mark; wave 0, which writes the root, is through after every wave it waited for) and overwrites the root
     // position of the block's envs with NaN: the observation kernel then produces NaN observations and rewards for them.
-    if (s_flag[15] != 0) {
+    if (__hip_atomic_load(&s_flag[15], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) {
         float *o = buf.char_root_pos + 3 * (size_t)e;
         const float qn = __builtin_nanf("");
         o[0] = qn; o[1] = qn; o[2] = qn;
