@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PARC_ABI_VERSION 2
+#define PARC_ABI_VERSION 3
 #define PARC_MAX_BODIES 16   /* 15 quats + root position share one 16-lane group */
 #define PARC_MAX_DOFS 40     /* dof velocities live in floats [88,128) of a 128-float frame record */
 #define PARC_MAX_TAR_STEPS 6 /* 2 + steps skeletons <= 8 lane groups of 8 */
@@ -128,6 +128,11 @@ typedef struct {
     int32_t enable_dynamics;                 /* 0 = kinematic-only step (state injected by the caller) */
     ParcDynamicsParams dynamics;             /* used when enable_dynamics */
     uint64_t seed;
+    /* `contact_bodies` (ig_parkour_env.py:62, dm_env_default.yaml:8; [] by default): bit b set = body b may touch the ground.  Non-zero
+     * switches on the fall rule of compute_done (mgdm_dm_util.py:349-360): FAIL when some OTHER body carries a contact-force component
+     * above 0.1 and some other body is lower than termination_height above the terrain under it (RefCharEnv.update_done :147-152). */
+    uint32_t contact_body_mask;
+    float termination_height;                /* ig_parkour_env.py:63 */
 } ParcEnvConfig;
 
 /* Motion clips as MotionLib._load_motion_file receives them (motion_lib.py:255-401); the library

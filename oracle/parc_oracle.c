@@ -502,13 +502,26 @@ void orc_ray_points_cone(float dx, int num_neg, int num_pos, int rays_neg, int r
 /* ------------------------------------------------------------------------------------------
  * a17..a19 standalone pieces
  * ---------------------------------------------------------------------------------------- */
-/* mgdm_dm_util.py:335-402 with contact_bodies == [] (dm_env_default.yaml:4) */
+/* mgdm_dm_util.py:335-402.  contact_force / termination_heights ([B] each) are only read when contact_bodies != []
+ * (:349-360; termination_heights = terrain height under each body + termination_height, RefCharEnv.update_done :147-152) */
 static int32_t compute_done1(const OrcEnvCfg *cfg, int B, float time, const float *root_rot, const float *body_pos,
-                             const float *tar_root_rot, const float *tar_body_pos) {
+                             const float *tar_root_rot, const float *tar_body_pos, const float *contact_force,
+                             const float *termination_heights) {
     int32_t done = ORC_DONE_NULL;
     if (time >= cfg->episode_length) done = ORC_DONE_TIME;
     if (cfg->enable_early_termination) {
         int failed = 0;
+        if (cfg->num_contact_bodies > 0 && contact_force && termination_heights) {
+            int fall_contact = 0, fall_height = 0;
+            for (int b = 0; b < B; ++b) {
+                int is_cb = 0;
+                for (int k = 0; k < cfg->num_contact_bodies; ++k) is_cb = is_cb || cfg->contact_body_ids[k] == b;
+                if (is_cb) continue; /* masked_contact_buf[:, contact_body_ids] = 0; fall_height[:, contact_body_ids] = False */
+                for (int k = 0; k < 3; ++k) if (fabsf(contact_force[3 * b + k]) > 0.1f) fall_contact = 1;
+                if (body_pos[3 * b + 2] < termination_heights[b]) fall_height = 1;
+            }
+            failed = failed || (fall_contact && fall_height);
+        }
         if (cfg->pose_termination) {
             int pose_fail = 0;
             for (int b = 1; b < B; ++b) {
@@ -545,7 +558,7 @@ void orc_compute_done(const OrcEnvCfg *cfg, int B, const float *time, const floa
                       const float *tar_root_rot, const float *tar_body_pos, int32_t *done, int n) {
     for (int i = 0; i < n; ++i)
         done[i] = compute_done1(cfg, B, time[i], root_rot + 4 * i, body_pos + (size_t)3 * B * i, tar_root_rot + 4 * i,
-                                tar_body_pos + (size_t)3 * B * i);
+                                tar_body_pos + (size_t)3 * B * i, NULL, NULL);
 }
 
 /* mgdm_dm_util.py:498-518 */
@@ -796,9 +809,17 @@ void orc_env_post_physics_step(const OrcChar *c, const OrcMotionLib *lib, const 
         rot_to_dof1(c, s->ref_joint_rot + (size_t)4 * J * e, s->ref_dof_pos + (size_t)D * e);
         compute_obs1(c, lib, cfg, s, e);
         update_reward1(c, cfg, s, e);
-        /* RefCharEnv.update_done mgdm_dm_util.py:147 */
+        /* RefCharEnv.update_done mgdm_dm_util.py:147-152: the terrain height under every body (global xy = env-local + env offset) */
+        float term_h[16];
+        if (cfg->num_contact_bodies > 0)
+            for (int b = 0; b < B; ++b) {
+                const float *bp = s->char_body_pos + 3 * ((size_t)B * e + b);
+                float gxy[2] = {bp[0] + cfg->env_offsets[3 * e + 0], bp[1] + cfg->env_offsets[3 * e + 1]};
+                term_h[b] = hf_val1(t, gxy) + cfg->termination_height;
+            }
         s->done[e] = compute_done1(cfg, B, s->time_buf[e], s->char_root_rot + 4 * e, s->char_body_pos + (size_t)3 * B * e,
-                                   s->ref_root_rot + 4 * e, s->ref_body_pos + (size_t)3 * B * e);
+                                   s->ref_root_rot + 4 * e, s->ref_body_pos + (size_t)3 * B * e,
+                                   s->contact_forces + (size_t)3 * B * e, term_h);
     }
 }
 

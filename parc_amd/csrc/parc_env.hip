@@ -78,6 +78,8 @@ struct StepParams {
     float pose_w, vel_w, root_pos_w, root_vel_w, key_pos_w;
     float root_pos_term_sq, root_rot_term;
     int early_term, pose_term, track_root, track_root_h, tracking, body_pos_from_fk, never_done;
+    unsigned fall_mask;   // contact_bodies != []: bit b = body b may touch the ground (0 = the fall rule is off)
+    float term_h;
     // terrain
     const float *hf; int X, Y; float min_x, min_y, dx, dy; int tile_r;
     float rdx, rdy;      // correctly rounded 1/dx, 1/dy (host): the ray loop divides by multiply + one exact correction
@@ -652,6 +654,20 @@ __global__ __launch_bounds__(64, 5) void k_env_post(const StepParams P, const in
             bad = (dx * dx + dy * dy + dz * dz) > lim * lim;
         }
         const bool pose_fail_any = __ballot(bad) != 0ull;
+        // fall rule (contact_bodies != [], mgdm_dm_util.py:349-360): a contact-force component above 0.1 on a body that is not a contact body
+        // AND such a body lower than termination_height above the terrain under it (global xy = env-local + env offset, :147-152)
+        bool fallen = false;
+        if (P.fall_mask != 0u) { // uniform
+            bool fc = false, fh = false;
+            if (lane >= 32 && lane < 32 + B && !((P.fall_mask >> (lane - 32)) & 1u))
+                fc = fabsf(aux0) > 0.1f || fabsf(aux1) > 0.1f || fabsf(aux2) > 0.1f;
+            if (lane < B && !((P.fall_mask >> lane) & 1u)) {
+                const float4 bp = s_cbp[lane];
+                const int ix = min(max(cell_index(bp.x + eox, P.min_x, P.dx), 0), P.X - 1), iy = min(max(cell_index(bp.y + eoy, P.min_y, P.dy), 0), P.Y - 1);
+                fh = bp.z < P.hf[(size_t)ix * P.Y + iy] + P.term_h;
+            }
+            fallen = (__ballot(fc) != 0ull) && (__ballot(fh) != 0ull);
+        }
         const float root_rot_angle = lane_value(dang, J);
         va = row_sum16(va); vb = row_sum16(vb);
         const float pose_err = lane_value(va, 0), csum = lane_value(va, 32), key_err = lane_value(va, 48);
@@ -686,7 +702,7 @@ __global__ __launch_bounds__(64, 5) void k_env_post(const StepParams P, const in
         int done = PARC_DONE_NULL;
         if (time >= P.episode_length) done = PARC_DONE_TIME;
         if (P.early_term) {
-            bool failed = false;
+            bool failed = fallen;
             if (P.pose_term) {
                 bool pf = pose_fail_any;
                 if (P.track_root) {
@@ -695,7 +711,7 @@ __global__ __launch_bounds__(64, 5) void k_env_post(const StepParams P, const in
                     pf = pf || (ex * ex + ey * ey + ez * ez) > P.root_pos_term_sq;
                     pf = pf || fabsf(root_rot_angle) > P.root_rot_term;
                 }
-                failed = pf;
+                failed = failed || pf;
             }
             if (!(time > 1e-5f)) failed = false;
             if (failed) done = PARC_DONE_FAIL;
@@ -1496,6 +1512,7 @@ extern "C" int parc_env_create(const ParcEnvConfig *cfg, ParcEnv **out) {
     sp.root_rot_term = cfg->root_rot_termination_angle;
     sp.early_term = cfg->enable_early_termination; sp.pose_term = cfg->pose_termination; sp.track_root = cfg->track_root;
     sp.track_root_h = cfg->track_root_h; sp.tracking = cfg->report_tracking_error; sp.body_pos_from_fk = cfg->body_pos_from_fk;
+    sp.fall_mask = cfg->contact_body_mask & ((1u << B) - 1u); sp.term_h = cfg->termination_height;
     if (!cfg->track_root) { delete e; return fail(PARC_ERR_INVALID, "track_root=false is not supported"); }
 
     auto up = [&](void **dst, const void *src, size_t bytes) -> hipError_t {

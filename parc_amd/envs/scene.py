@@ -136,8 +136,6 @@ def build_scene(config: dict, num_envs: int, device_index: int = 0, env_id_base:
         raise ValueError("global_obs / global_root_height_obs variants are not supported")
     if not env_config.get("enable_tar_obs", True):
         raise ValueError("enable_tar_obs: false is not supported")
-    if env_config.get("contact_bodies", []):
-        raise ValueError("contact_bodies must be [] (fall-contact termination is not implemented)")
     if env_config.get("control_mode", "pd") != "pd":
         raise ValueError("only control_mode: pd is supported")
     _ = env_config["debug_visuals"], env_config["ref_char_offset"], env_config["camera_mode"]
@@ -243,6 +241,15 @@ def build_scene(config: dict, num_envs: int, device_index: int = 0, env_id_base:
     cfg.body_pos_from_fk = int(env_config.get("hip", {}).get("body_pos_from_fk", True))
     fill_dynamics(cfg.dynamics, cm, env_config, config.get("sim", {}))
     cfg.seed = seed
+    # contact_bodies (ig_parkour_env.py:62-63): the bodies that may touch the ground; non-empty switches on the fall termination
+    names = cm.get_body_names()
+    mask = 0
+    for nm in env_config.get("contact_bodies", []) or []:
+        if nm not in names:
+            raise ValueError(f"contact_bodies: unknown body {nm!r}")
+        mask |= 1 << names.index(nm)
+    cfg.contact_body_mask = mask
+    cfg.termination_height = float(env_config["termination_height"])
 
     from collections import OrderedDict
     J, K, S, R = B - 1, len(key_body_ids), len(tar_obs_steps), ray.shape[0]

@@ -533,6 +533,53 @@ def gen_env_step(m):
     save("env_step", **arrs)
 
 
+def gen_env_step_fall(m):
+    """`contact_bodies: [right_foot, left_foot]` (mgdm_dm_util.py:349-360): a fall = a contact force above 0.1 on some body other
+    than those AND some such body lower than `termination_height` above the terrain under it (dm_env.py:628-635 looks the terrain
+    up per body).  Same scene and reset as env_step.npz; one step on injected state with the four combinations spread over the rows."""
+    cfg = env_config()
+    cfg["env"]["pose_termination"] = False   # isolate the fall rule: moving a body to a chosen height would trip the pose rule as well
+    n = 64
+    env, dm = build_harness(m, CLIPS, n, cfg)
+    feet = [m.get_body_id("right_foot"), m.get_body_id("left_foot")]
+    env._contact_body_ids = torch.tensor(feet, dtype=torch.long)
+    g = torch.Generator().manual_seed(11)
+    torch.manual_seed(321)
+    dm.reset(torch.arange(n))
+    env._refresh_sim_tensors()
+    env._update_observations(torch.arange(n))
+    env._timestep_buf[:] = torch.randint(1, 40, (n,), generator=g, dtype=torch.int32)
+    inject_state(env, dm, m, g, noise=0.02)
+    # ground height under every body (the same lookup update_done does) to place bodies relative to it
+    gpos = env._char_rigid_body_pos[..., 0:2] + env._env_offsets[:, 0:2].unsqueeze(1)
+    inds = dm._terrain.get_grid_index(gpos)
+    ground = dm._terrain.hf[inds[..., 0], inds[..., 1]]
+    f = torch.zeros(n, 15, 3)
+    for e in range(n):
+        kind = e % 4
+        # feet may always push (they are contact bodies): must never count
+        f[e, feet[0]] = torch.tensor([0.0, 0.0, 300.0]); f[e, feet[1]] = torch.tensor([5.0, -3.0, 200.0])
+        b_f, b_h = 1 + (e % 8), 3 + (e % 6)          # bodies 1..8 / 3..8: never a foot
+        if kind in (1, 3):                            # contact on a non-contact body (one component just above / below 0.1)
+            f[e, b_f] = torch.tensor([0.0, 0.1001 if e % 8 < 4 else -0.35, 0.0])
+        if kind == 0:
+            f[e, b_f] = torch.tensor([0.0999, -0.0999, 0.05])   # below the threshold on every component: no contact
+        if kind in (2, 3):                            # some non-contact body lower than termination_height above its ground
+            env._char_rigid_body_pos[e, b_h, 2] = ground[e, b_h] - env._env_offsets[e, 2] * 0 + 0.149
+        else:
+            env._char_rigid_body_pos[e, 1:, 2] = torch.maximum(env._char_rigid_body_pos[e, 1:, 2], ground[e, 1:] + 0.151)
+            env._char_rigid_body_pos[e, feet, 2] = ground[e, feet] + 0.02   # low feet never count
+    env._char_contact_forces[:] = f
+    arrs = {"contact_body_ids": np.array(feet, np.int64), "termination_height": np.float32(cfg["env"]["termination_height"]),
+            "pose_termination": np.int32(0)}
+    arrs.update(state_dict(env, dm, "in_"))
+    ig_env.IGEnv._post_physics_step(env)
+    arrs.update(out_dict(env, dm, "out_"))
+    save("env_step_fall", **arrs)
+    d = npy(env._done_buf)
+    print("fall fixture: done histogram", np.bincount(d, minlength=4), "rows kind 3 failed:", d[3::4])
+
+
 def gen_done_table():
     g = torch.Generator().manual_seed(5)
     n = 128
@@ -569,3 +616,4 @@ if __name__ == "__main__":
     gen_terrain_wide(model)
     gen_done_table()
     gen_env_step(model)
+    gen_env_step_fall(model)

@@ -44,7 +44,7 @@ def dof_err_w_from_joint(char_golden, joint_err_w):
     return w
 
 
-def default_cfg(oracle, num_envs, ray_points=None, env_offsets=None, motion_offsets=None):
+def default_cfg(oracle, num_envs, ray_points=None, env_offsets=None, motion_offsets=None, **kw):
     cg = golden("char_model")
     if ray_points is None:
         ray_points = golden("terrain_lookup")["ray_points"]
@@ -54,7 +54,7 @@ def default_cfg(oracle, num_envs, ray_points=None, env_offsets=None, motion_offs
         motion_offsets = np.zeros((1, 1, 2), np.float32)
     return oracle.make_cfg(num_envs, KEY_BODY_IDS, TAR_OBS_STEPS, ray_points, 30, 10.0, -3.0, 3.0,
                            [0.5, 0.1, 0.15, 0.1, 0.15], JOINT_ERR_W, dof_err_w_from_joint(cg, JOINT_ERR_W),
-                           [5.0] * 15, POSE_TERM_DIST, 0.6, 1.309, env_offsets, motion_offsets)
+                           [5.0] * 15, POSE_TERM_DIST, 0.6, 1.309, env_offsets, motion_offsets, **kw)
 
 
 def build_oracle_scene(oracle, orc_char, g):

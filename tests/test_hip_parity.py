@@ -68,7 +68,7 @@ def test_library_loaded_is_in_tree(genv):
     from parc_amd import lib as L
     assert L.LIB_PATH.endswith("parc_amd/libparc_env.so")
     from parc_amd import lib as L2
-    assert genv[0]._lib.parc_abi_version() == L2.ABI_VERSION == 2
+    assert genv[0]._lib.parc_abi_version() == L2.ABI_VERSION == 3
 
 
 def test_kin_ops_vs_golden(genv):
@@ -155,6 +155,39 @@ def test_env_step_vs_reference_golden(genv):
         assert obs is env._obs_buf and rew is env._reward_buf and done is env._done_buf
         assert set(info["rewards"].keys()) == {"pose_r", "vel_r", "root_pos_r", "root_vel_r", "key_pos_r", "contact_penalty", "total_r"}
         _check_step_outputs(env, g, f"s{s}_out_")
+
+
+def test_fall_termination_with_contact_bodies_vs_reference_golden(tmp_path):
+    """`contact_bodies: [right_foot, left_foot]` (off the default config; rejected with an error until round 3): the fall rule of
+    compute_done (mgdm_dm_util.py:349-360) incl. the per-body terrain lookup (:147-152) against the reference's own
+    `_post_physics_step` (env_step_fall.npz: the four combinations of contact on a non-contact body / a non-contact body below the
+    termination height; pose termination off so that only the fall rule, the time limit and the motion end decide)."""
+    from gpu_helpers import default_config, write_motion_yaml, inject, to_np, GOLDEN_WEIGHTS
+    from parc_amd.envs.hip_parkour_env import HipParkourEnv
+    g, g0 = golden("env_step_fall"), golden("env_step")
+    names = ["pelvis", "torso", "head", "right_upper_arm", "right_lower_arm", "right_hand", "left_upper_arm", "left_lower_arm", "left_hand",
+             "right_thigh", "right_shin", "right_foot", "left_thigh", "left_shin", "left_foot"]
+    outs = {}
+    for fall in (True, False):
+        cfg = default_config()
+        cfg["env"]["dm"]["motion_file"] = write_motion_yaml(tmp_path, [str(c) for c in g0["clips"]], GOLDEN_WEIGHTS)
+        cfg["env"]["hip"]["body_pos_from_fk"] = False
+        cfg["env"]["pose_termination"] = bool(g["pose_termination"])
+        cfg["env"]["contact_bodies"] = [names[int(b)] for b in g["contact_body_ids"]] if fall else []
+        assert abs(cfg["env"]["termination_height"] - float(g["termination_height"])) < 1e-7
+        env = HipParkourEnv(cfg, 64, "cuda:0", False, mirror_ref_state=fall)
+        inject(env, g, "in_")
+        env.step(None)
+        outs[fall] = to_np(env._done_buf).copy()
+        if fall:
+            assert np.array_equal(outs[fall], g["out_done"])
+            close(env.get_fail_rates().numpy(), g["out_fail_rates"], tol=0, what="fail_rates")
+            err = np.abs(to_np(env._obs_buf) - g["out_obs"])
+            ray_bad = np.abs(to_np(env._obs_buf)[:, 871:] - g["out_obs"][:, 871:]) > TOL
+            err[:, 871:][ray_bad] = 0
+            assert ray_bad.mean() < 2e-4 and err.max() <= TOL
+    assert (g["out_done"][3::4] == 1).all()
+    assert (outs[False] != outs[True]).sum() >= 8     # with contact_bodies = [] nobody falls (some of the 16 rows also reach their motion end)
 
 
 def test_env_reset_vs_reference_golden(genv):

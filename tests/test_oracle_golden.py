@@ -261,3 +261,31 @@ def test_torch_path_vs_golden(char_golden):
     close(o2[0].numpy(), w["root_pos"], tol=5e-6, what="wrap root_pos"); close(o2[4].numpy(), w["joint_rot"], tol=5e-6, what="wrap joint_rot")
     res = tp.step_path(cm, lib, ids[:64], times[:64].clamp(min=0.0), T(k["root_pos"][:64]), T(k["root_rot"][:64]), T(k["dof"][:64]), 1.0 / 30.0)
     assert res[2].shape == (64 * 6, 15, 3) and all(torch.isfinite(r).all() for r in res)
+
+
+def test_fall_termination_with_contact_bodies_vs_reference(oracle, orc_char):
+    """`contact_bodies: [right_foot, left_foot]` (not the default config): the fall rule of compute_done (mgdm_dm_util.py:349-360) with
+    the per-body terrain lookup of RefCharEnv.update_done (:147-152), against the reference's own `_post_physics_step` on the four
+    combinations of (contact on a non-contact body, a non-contact body below the termination height); pose termination off in
+    the fixture so that only the fall rule, the time limit and the motion end decide."""
+    from helpers import build_oracle_scene, default_cfg, load_state_into
+    g = golden("env_step_fall")
+    g0 = golden("env_step")
+    sc = build_oracle_scene(oracle, orc_char, g0)
+    n = g0["env_offsets"].shape[0]
+    cfg = default_cfg(oracle, n, g0["ray_points"], g0["env_offsets"], g0["motion_offsets"], pose_termination=bool(g["pose_termination"]),
+                      contact_body_ids=[int(b) for b in g["contact_body_ids"]], termination_height=float(g["termination_height"]))
+    st = sc["state"]
+    load_state_into(st, g, "in_")
+    oracle.env_post_physics_step(orc_char, sc["lib"], sc["terrain"], cfg, st)
+    oracle.env_update_curriculum(sc["lib"], cfg, st)
+    assert np.array_equal(st["done"], g["out_done"])
+    assert (g["out_done"][3::4] == 1).all() and (g["out_done"] == 0).sum() > 30     # the fixture exercises both outcomes
+    np.testing.assert_allclose(st["obs"], g["out_obs"], atol=1e-5)
+    np.testing.assert_array_equal(st["fail_rates"], g["out_fail_rates"])
+    # counterfactual: with contact_bodies = [] nobody falls
+    cfg0 = default_cfg(oracle, n, g0["ray_points"], g0["env_offsets"], g0["motion_offsets"], pose_termination=False)
+    load_state_into(st, g, "in_")
+    oracle.env_post_physics_step(orc_char, sc["lib"], sc["terrain"], cfg0, st)
+    oracle.env_update_curriculum(sc["lib"], cfg0, st)
+    assert (st["done"] != g["out_done"]).sum() >= 8      # (some of the sixteen fall rows also reach their motion end)
