@@ -215,29 +215,28 @@ def cpu_baseline(env, seconds, dynamics_on, actions):
            "sample": f"{steps} {'full (dynamics + obs/reward/done)' if dynamics_on else 'kinematic'} steps x {n} envs, C/C++ oracle "
                      "(scalar, -O2, one thread per core), same scene and state"}
     try:
-        out["torch_path"] = torch_path_baseline(env, max(3.0, 0.5 * seconds), st)
+        out["torch_path"] = torch_path_baseline(env, max(3.0, 0.5 * seconds), st, oracle, lib)
     except Exception as ex:  # a baseline leg must never take the benchmark down
         out["torch_path"] = {"error": repr(ex)}
     return out
 
 
-def torch_path_baseline(env, seconds, st):
+def torch_path_baseline(env, seconds, st, oracle, orc_lib):
     """The north star's "reference CPU-PyTorch motion_lib / kin_char_model path": oracle/torch_path.py issues the reference's batched
     tensor-op sequence (calc_motion_frame at t and the six look-ahead times, dof <-> rot, the three FK calls of a step) on CPU
     tensors with all host cores.  Pinned against the reference's golden vectors by tests/test_oracle_golden.py."""
-    import ctypes as C
     import numpy as np
     import torch
     from oracle import torch_path as tp
     from conftest import golden
-    from parc_amd import lib as L
     cg = golden("char_model")
     cm = tp.CharModel(cg["parent"], cg["local_translation"], cg["local_rotation"], cg["joint_type"], cg["joint_axis"], cg["dof_idx"], int(cg["dof_size"]))
     sc = env._scene
     clips = sc.clips
     F = sum(c.num_frames for c in clips)
-    rv, rav, dv = np.zeros((F, 3), np.float32), np.zeros((F, 3), np.float32), np.zeros((F, 28), np.float32)
-    L.check(env._lib.parc_env_get_frame_vel_tables(env._handle, L.np_f32p(rv), L.np_f32p(rav), L.np_f32p(dv)))
+    # load-time velocity tables of the CPU oracle's own motion library (MotionLib._load_motion_file :318-327), not the product's
+    rv, rav, dv = (oracle.mlib_array(orc_lib, "frame_root_vel", (F, 3)), oracle.mlib_array(orc_lib, "frame_root_ang_vel", (F, 3)),
+                   oracle.mlib_array(orc_lib, "frame_dof_vel", (F, 28)))
     nf = np.array([c.num_frames for c in clips], np.int64)
     tables = dict(frame_root_pos=np.concatenate([c.root_pos for c in clips]), frame_root_rot=np.concatenate([c.root_rot for c in clips]),
                   frame_joint_rot=np.concatenate([c.joint_rot for c in clips]), frame_root_vel=rv, frame_root_ang_vel=rav, frame_dof_vel=dv,

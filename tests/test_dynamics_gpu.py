@@ -432,3 +432,28 @@ def test_flag_timeout_is_counted_and_poisons_the_state(tmp_path):
     script.write_text(_BREAK_BODY.format(repo=REPO))
     p = subprocess.run([sys.executable, str(script)], env=dict(os.environ, PARC_ENV_LIB=lib), capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "BREAKFLAG_OK" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])
+
+
+def test_soak_full_step_at_65536_envs():
+    """1 500 full control steps (+ reset of finished envs) at the headline size under noisy actions (tools/soak.py, shortened): the state
+    stays finite, nothing is launched, no hand-off of the dynamics kernel times out, episodes keep ending and restarting."""
+    import torch
+    from gpu_helpers import default_config
+    from parc_amd.envs.hip_parkour_env import HipParkourEnv
+    n = 65536
+    env = HipParkourEnv(default_config(), n, "cuda:0", False, seed=3, enable_dynamics=True, mirror_ref_state=False)
+    gen = torch.Generator(device="cuda:0"); gen.manual_seed(17)
+    env.reset()
+    acts = [_bench_actions(env, gen) for _ in range(8)]
+    ended = 0
+    for it in range(1500):
+        _, _, done, _ = env.step(acts[it & 7])
+        if it % 250 == 249:
+            _finite_state(env)
+            assert float(env._char_root_vel.norm(dim=-1).max()) < 60.0 and float(env._char_contact_forces.abs().max()) < 2.0e5
+            ended += int((done != 0).sum())
+        env.reset_done()
+    assert ended > 1000
+    assert env.dynamics_timeouts() == 0
+    fr = env.get_fail_rates().numpy()
+    assert np.isfinite(fr).all() and fr.min() > 0.0 and fr.max() <= 1.0
