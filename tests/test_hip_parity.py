@@ -532,6 +532,26 @@ def test_dynamics_kernels_agree(tmp_path, monkeypatch, n):
                 assert np.abs(a - b).max() <= tol[nm], (it, kern, nm, np.abs(a - b).max())
             fa, fb = to_np(ref._char_contact_forces), to_np(envs[kern]._char_contact_forces)
             assert np.abs(fa - fb).max() <= 1.0 + 1e-3 * np.abs(fa).max(), (it, kern, np.abs(fa - fb).max())
+    if n >= 512:
+        # the agreement above includes the column-edge candidates of shafts / sole edges (round 3): they ARE active in this scene --
+        # the same roll-out with the segments switched off (developer switch) must differ for some env
+        monkeypatch.setenv("PARC_DYN_KERNEL", "wave"); monkeypatch.setenv("PARC_DYN_SEGMENTS", "none")
+        cfg = default_config()
+        cfg["env"]["dm"]["motion_file"] = write_motion_yaml(tmp_path, ["civilization", "sfu"], [1.0, 1.0])
+        noseg = HipParkourEnv(cfg, n, "cuda:0", False, seed=9, enable_dynamics=True, mirror_ref_state=True)
+        monkeypatch.delenv("PARC_DYN_SEGMENTS")
+        withseg = HipParkourEnv(cfg, n, "cuda:0", False, seed=9, enable_dynamics=True, mirror_ref_state=True)
+        for e in (noseg, withseg):
+            e.reset()
+        g2 = torch.Generator(device="cuda:0"); g2.manual_seed(3)
+        differ = 0
+        for it in range(12):
+            act = (withseg._char_dof_pos + 0.1 * torch.randn(withseg._char_dof_pos.shape, device="cuda:0", generator=g2)).contiguous()
+            for nm in state + ["_char_contact_forces"]:
+                getattr(noseg, nm).copy_(getattr(withseg, nm))
+            withseg.step(act); noseg.step(act)
+            differ += int(((withseg._char_dof_vel - noseg._char_dof_vel).abs().amax(dim=1) > 1e-2).sum())
+        assert differ > 0, "no env of the scene had a shaft / sole edge on a column edge in 12 steps"
 
 
 def test_recorder_writes_motion_terrain_files(tmp_path):
