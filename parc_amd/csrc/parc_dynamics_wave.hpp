@@ -181,7 +181,7 @@ inline bool build_wave_tables(const DynModel &M, const CoopTables &C, WaveTables
     for (int k = 0; k < M.nseg; ++k) { for (int a = 0; a < 3; ++a) { W.seg[k][a] = M.seg_a[k][a]; W.seg[k][4 + a] = M.seg_b[k][a]; } W.seg[k][3] = M.seg_r[k]; }
     for (int b = 0; b < M.B; ++b) {
         W.c[b].nsg = C.nsg[b]; W.c[b].sg0 = C.sg0[b];
-        if (C.npt[b] + C.nsg[b] > 32) return false; // one hit bit per candidate
+        if (C.npt[b] + C.nsg[b] > 32) return false;
     }
     if (wv_lds_floats(off) * (int)sizeof(float) > 160 * 1024) return false; // does not fit one CU's LDS: the caller falls back to the chain-parallel kernel
     return true;
@@ -209,7 +209,9 @@ __device__ unsigned long long g_wave_tl[4][16];
 
 #ifdef PARC_STAMPS
 __device__ unsigned long long g_wave_stamps[4][16];
-__device__ unsigned long long g_wave_cnt[16][8]; // filled by -DPARC_COUNTS builds only: // per body: lanes, near lanes, waves with a near lane, hit lanes, hit bits, slow lanes, pass-2 iterations, waves
+__device__ unsigned long long g_wave_cnt[16][8]; // filled by -DPARC_COUNTS builds only, per body: lanes, near lanes (body window reaches down to its 5x5 maximum), waves with a
+                                                 // near lane, (lane, candidate) pairs that enter the narrow phase, candidates of the body (points + segments) x waves,
+                                                 // slow lanes, narrow-phase executions (a candidate with at least one lane), waves
 #define WSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); wacc[i] += t_ - wlast; wlast = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
 // pin: the 27 values of (IA, pA) must be complete before the stamp that follows (keeps arithmetic from sinking past it)
 #define WPIN(IA_, pA_) do { for (int i_ = 0; i_ < 21; ++i_) asm volatile("" : "+v"((IA_).s[i_])); for (int i_ = 0; i_ < 6; ++i_) asm volatile("" : "+v"((pA_).a[i_])); } while (0)
@@ -366,6 +368,9 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
     const int npt = W.c[b].npt, pt0 = W.c[b].pt0, nsg = W.c[b].nsg, sg0 = W.c[b].sg0;
     const float hx = 0.5f * Tp.dx, hy = 0.5f * Tp.dy;
     bool slow = false;
+#ifdef PARC_COUNTS
+    int cnt_pairs = 0, cnt_exec = 0; // wave-uniform
+#endif
     // edge candidate of segment ks (patch frame).  FAST: heights from the staged patch with clamped indices -- both ends of a segment are
     // collision points of the body, so a lane whose segment leaves the inner patch is a `slow` lane below, which uses the other variant
     // (global memory outside the patch)
@@ -472,6 +477,9 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
             const v3 x = r + mulv(R, mk(cur.x, cur.y, cur.z));
             const v3 g = x + rootp;
             const bool mine = !slow && !(g.z - cur.r > hmax); // the sphere reaches down to the highest column of the body's window
+#ifdef PARC_COUNTS
+            cnt_pairs += __popcll(__ballot(mine)); cnt_exec += __any(mine) ? 1 : 0;
+#endif
             if (__any(mine)) { // uniform
                 if (mine) narrow(x, g, cur.r, 1.f);
             }
@@ -488,6 +496,9 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
             v3 Q = rootp;
             const float wq = seg_point(sg0 + si, Q);
             const bool has = wq > 0.f && !slow && !(Q.z - W.seg[sg0 + si][3] > hmax);
+#ifdef PARC_COUNTS
+            cnt_pairs += __popcll(__ballot(has)); cnt_exec += __any(has) ? 1 : 0;
+#endif
             if (!__any(has)) continue; // uniform
             if (has) narrow(Q - rootp, Q, W.seg[sg0 + si][3], wq);
         }
@@ -526,6 +537,17 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
         }
     }
     B.fcon = fsum;
+#ifdef PARC_COUNTS
+    {
+        const unsigned long long m_near = __ballot(hmax > -1.0e38f), m_slow = __ballot(slow);
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&g_wave_cnt[b][0], 64ull); atomicAdd(&g_wave_cnt[b][1], (unsigned long long)__popcll(m_near));
+            atomicAdd(&g_wave_cnt[b][2], m_near ? 1ull : 0ull); atomicAdd(&g_wave_cnt[b][3], (unsigned long long)cnt_pairs);
+            atomicAdd(&g_wave_cnt[b][4], (unsigned long long)(npt + nsg)); atomicAdd(&g_wave_cnt[b][5], (unsigned long long)__popcll(m_slow));
+            atomicAdd(&g_wave_cnt[b][6], (unsigned long long)cnt_exec); atomicAdd(&g_wave_cnt[b][7], 1ull);
+        }
+    }
+#endif
     WPIN(IA, pA);
     WSTAMP(6);  // segments (+ the exhaustive path of lanes outside the patch)
 }

@@ -45,8 +45,10 @@ c = (C.c_double * 128)()
 env._lib.parc_env_debug_wave_counts.argtypes = [C.POINTER(C.c_double)]
 env._lib.parc_env_debug_wave_counts(c)
 bn = env._kin_char_model.get_body_names()
-print("%-18s %8s %8s %8s %8s %8s %8s" % ("body", "near", "wv_near", "hit", "bits/hit", "slow", "it2/wave"), file=sys.stderr)
+# -DPARC_COUNTS builds: how much of the contact narrow phase a wave executes vs how many lanes need it
+print("%-18s %10s %10s %12s %14s %8s" % ("body", "near lanes", "near waves", "lane use", "executed/cands", "slow"), file=sys.stderr)
 for b in range(len(bn)):
     r = [c[b * 8 + i] for i in range(8)]
     if r[0] == 0: continue
-    print("%-18s %8.4f %8.4f %8.4f %8.2f %8.5f %8.2f" % (bn[b], r[1] / r[0], r[2] / r[7], r[3] / r[0], r[4] / max(r[3], 1), r[5] / r[0], r[6] / r[7]), file=sys.stderr)
+    # lane use = (lane, candidate) pairs that needed the narrow phase / (64 lanes x executed candidates)
+    print("%-18s %10.4f %10.4f %12.4f %8.2f / %-4.0f %8.5f" % (bn[b], r[1] / r[0], r[2] / r[7], r[3] / max(64.0 * r[6], 1.0), r[6] / r[7], r[4] / r[7], r[5] / r[0]), file=sys.stderr)
