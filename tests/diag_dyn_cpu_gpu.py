@@ -1,7 +1,8 @@
-"""Dev tool: k_dynamics_wave vs the host build of the same equations (oracle/dyn_oracle.cpp), per-env error statistics and what the
+"""Calibration script of tests/test_hip_parity.py::test_dynamics_kernel_matches_cpu_build (lives under tests/ because it uses the CPU oracle,
+which only the tests, smoke() and bench.py's cpu_baseline leg may touch): k_dynamics_wave vs the host build of the same equations (oracle/dyn_oracle.cpp), per-env error statistics and what the
 outlier envs have in common (calibrates tests/test_hip_parity.py::test_dynamics_kernel_matches_cpu_build)."""
 import os, sys, tempfile, pathlib
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import numpy as np, torch
 from gpu_helpers import default_config, write_motion_yaml, to_np

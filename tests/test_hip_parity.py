@@ -417,7 +417,7 @@ def test_dynamics_kernel_matches_cpu_build(tmp_path):
                   contact_force=np.zeros((n, 15, 3), np.float32))
         env.step(act)
         d.step(hf, mp, dxdy, st, to_np(act), sc.env_offsets)
-        # Evidence-based allowance (tools/dyn_cpu_gpu_diag.py, round 3, MI355X, 2 048 envs x 4 steps): NO env beyond 20 x tol, worst env
+        # Evidence-based allowance (tests/diag_dyn_cpu_gpu.py, round 3, MI355X, 2 048 envs x 4 steps): NO env beyond 20 x tol, worst env
         # 7 x tol (dof_vel, step 4), 99.9 % quantile <= 0.15 tol.  An env may exceed 20 x tol only if the two builds disagree about WHICH
         # bodies are in contact (a point within rounding of a surface / cell face picked the other branch) -- checked, not assumed --
         # and even then its root stays within 1 cm; at most 0.2 % of the envs (2 x nothing, rounded up to a handful).
