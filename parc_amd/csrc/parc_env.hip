@@ -73,6 +73,7 @@ struct MotionMeta { // 32 B
 
 struct StepParams {
     int N, B, J, D, K, S, R, M, T;
+    int lds_wave_floats; // dynamic LDS per wave of k_env_post
     int obs_dim, off_dofvel, off_key, off_tar, tar_w, off_tarc, off_cc, off_hf;
     float dt_f, episode_length, min_obs_h, max_obs_h;
     float pose_w, vel_w, root_pos_w, root_vel_w, key_pos_w;
@@ -219,6 +220,9 @@ __global__ __launch_bounds__(64) void k_env_prep(const StepParams P, const int64
 #endif
 #define MODE_STEP 0
 #define MODE_OBS 1
+#define ENVS_PER_BLOCK 4
+// orders the LDS traffic of ONE wave (see k_env_post): a compiler-level fence, no instruction
+#define WAVE_SYNC() asm volatile("" ::: "memory")
 #define RAY_UNROLL 8
 
 __device__ __forceinline__ float wave_sum(float v) { // butterfly over the 64 lanes; every lane gets the total
@@ -245,35 +249,50 @@ __device__ __forceinline__ float lane_value(float v, int l) { return __int_as_fl
 // the training configuration.  Their pointers and null checks then leave the kernel (20+ SGPRs: the kernel is at the SGPR limit and every
 // scalar spilled to a VGPR lane comes back as a VALU instruction).
 template <int MODE, bool MIRROR>
-__global__ __launch_bounds__(64, 5) void k_env_post(const StepParams P, const int64_t *__restrict__ env_ids,
+__global__ __launch_bounds__(256, 5) void k_env_post(const StepParams P, const int64_t *__restrict__ env_ids,
                                                  const int *__restrict__ env_ids32, const int *__restrict__ count_dev, int count,
                                                  unsigned long long *bump_calls) {
     // P arrives by value in the kernarg segment: its pointers are then known to be global (global_load / global_store
     // instead of flat_*, which would also tie up the LDS wait counter), its scalars are scalar loads where they are used
-    extern __shared__ __align__(16) float s_obs[]; // staged observation prefix [0, off_tarc)
+    // A workgroup is four waves = four envs (ENVS_PER_BLOCK).  Everything up to the reward is wave-private: each wave owns slice `wv` of
+    // the LDS arrays and orders its own LDS traffic with WAVE_SYNC (LDS executes a wave's instructions in order; only the compiler has
+    // to be kept from moving a read above the write of another lane).  The joint hierarchy is staged by every wave with the same values.
+    extern __shared__ __align__(16) float s_obs_all[]; // per wave: staged observation prefix [0, off_tarc) (+ the body rotations of the tracking error)
     __shared__ int s_tab_raw[HIER_STAGED_WORDS];
     const HierTables &s_tab = *reinterpret_cast<const HierTables *>(s_tab_raw); // only the staged members are touched through it
-    __shared__ float4 s_q[8][16];   // row r: quats 0..14 (0 = root), slot 15 = root position.  Target rows (r >= 2) hold lr (x) q for the joints
-    __shared__ float4 s_lq[2][16];  // rows 0, 1: lr (x) q of the joints (s_q keeps their raw quaternions for the reward)
-    __shared__ float4 s_fk[80];     // FK positions: rows 0,1 all bodies [r*16+b]; target rows key slots [32+(r-2)*8+k]
-    float4 *s_cbp = s_lq[0];        // simulator rigid-body positions of the character: written once the FK chains are through with s_lq
-    // (LDS budget: 5 120 B static + 3 072 B staged row = 8 192 B, i.e. 20 workgroups = 5 waves per SIMD on a CU's 160 KB)
-    __shared__ float s_cdofv[PARC_MAX_DOFS];
-    __shared__ float4 s_refvel[12]; // record float4 #20..: root_vel, root_ang_vel, dof_vel
-    __shared__ float s_refct[16];
-    __shared__ float s_cfn[16];
+    __shared__ float4 s_q_all[ENVS_PER_BLOCK][8][16];   // row r: quats 0..14 (0 = root), slot 15 = root position.  Target rows (r >= 2) hold lr (x) q for the joints
+    __shared__ float4 s_lq_all[ENVS_PER_BLOCK][2][16];  // rows 0, 1: lr (x) q of the joints (s_q keeps their raw quaternions for the reward)
+    __shared__ float4 s_fk_all[ENVS_PER_BLOCK][80];     // FK positions: rows 0,1 all bodies [r*16+b]; target rows key slots [32+(r-2)*8+k]
+    // (LDS budget: 864 B of tables + 4 x (4 416 B static + 3 072 B staged row) = 30.1 KB per workgroup: 5 workgroups = 5 waves per SIMD
+    // on a CU's 160 KB)
+    __shared__ float s_cdofv_all[ENVS_PER_BLOCK][PARC_MAX_DOFS];
+    __shared__ float4 s_refvel_all[ENVS_PER_BLOCK][12]; // record float4 #20..: root_vel, root_ang_vel, dof_vel
+    __shared__ float s_refct_all[ENVS_PER_BLOCK][16];
+    __shared__ float s_cfn_all[ENVS_PER_BLOCK][16];
 #ifdef PARC_STAMPS
-    __shared__ unsigned long long s_stamp[16];
+    __shared__ unsigned long long s_stamp_all[ENVS_PER_BLOCK][16];
+#endif
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    float *s_obs = s_obs_all + (size_t)wv * P.lds_wave_floats;
+    float4 (*s_q)[16] = s_q_all[wv];
+    float4 (*s_lq)[16] = s_lq_all[wv];
+    float4 *s_fk = s_fk_all[wv];
+    float4 *s_cbp = s_lq[0];        // simulator rigid-body positions of the character: written once the FK chains are through with s_lq
+    float *s_cdofv = s_cdofv_all[wv];
+    float4 *s_refvel = s_refvel_all[wv];
+    float *s_refct = s_refct_all[wv], *s_cfn = s_cfn_all[wv];
+#ifdef PARC_STAMPS
+    unsigned long long *s_stamp = s_stamp_all[wv];
 #endif
     float *s_tile = (float *)s_fk;  // the terrain tile is dead before FK writes s_fk
     float4 (*s_br)[16] = reinterpret_cast<float4 (*)[16]>(s_obs + ((P.off_tarc + 3) & ~3)); // body rotations of char/ref: only allocated
                                                                                             // (behind the staged prefix) when the tracking error is reported
 
-    const int lane = threadIdx.x;
     // the observation pass of a sampling reset closes the call: every block of the reset kernel has read the Philox call index by now
-    if (MODE == MODE_OBS && bump_calls && blockIdx.x == 0 && lane == 0) *bump_calls += 1ull;
+    if (MODE == MODE_OBS && bump_calls && blockIdx.x == 0 && threadIdx.x == 0) *bump_calls += 1ull;
     if (count_dev) count = *count_dev; // device-side list (reset_done): no host round trip
-    const int it = blockIdx.x;
+    const int it = blockIdx.x * ENVS_PER_BLOCK + wv;
     if (it >= count) return;
     int e = env_ids ? (int)env_ids[it] : (env_ids32 ? env_ids32[it] : it);
     e = __builtin_amdgcn_readfirstlane(e);
@@ -398,7 +417,7 @@ __global__ __launch_bounds__(64, 5) void k_env_post(const StepParams P, const in
     }
 #pragma unroll
     for (int i = 0; i < 5; ++i) { const int idx = lane + 64 * i; if (idx < ncell) s_tile[idx] = tilev[i]; }
-    __syncthreads();
+    WAVE_SYNC();
     STAMP(1);
 
     // ================= height rays (mgdm_dm_util.py:128-145; terrain_util.py:146-156) =================
@@ -557,7 +576,7 @@ __global__ __launch_bounds__(64, 5) void k_env_post(const StepParams P, const in
         const float *src = P.buf.char_body_pos + 3 * ((size_t)e * B + lane);
         bpx = src[0]; bpy = src[1]; bpz = src[2];
     }
-    __syncthreads();
+    WAVE_SYNC();
     STAMP(3);
 
     // ================= FK: row k = lane>>3, root-to-leaf chain c = lane&7 (kin_char_model.py:617-649) =================
@@ -589,7 +608,7 @@ __global__ __launch_bounds__(64, 5) void k_env_post(const StepParams P, const in
             }
         }
     }
-    __syncthreads();
+    WAVE_SYNC();
     if (lane < B) s_cbp[lane] = P.body_pos_from_fk ? s_fk[lane] : make_float4(bpx, bpy, bpz, 0.f);
     STAMP(4);
 
@@ -614,7 +633,7 @@ __global__ __launch_bounds__(64, 5) void k_env_post(const StepParams P, const in
     STAMP(5);
 
     if (MODE == MODE_STEP) {
-        __syncthreads(); // s_cbp
+        WAVE_SYNC(); // s_cbp
         // ---- reward terms, one per lane (mgdm_dm_util.py:270-333, 498-518).  Row layout of the two partial-sum registers:
         //   va: row 0 = joint pose terms (lane J of row 0 carries the root rotation angle, not summed), row 2 = contact terms,
         //       row 3 = key-body terms;  vb: rows 0..1 = dof velocity terms (and beyond, for D > 32).
@@ -775,7 +794,7 @@ __global__ __launch_bounds__(64, 5) void k_env_post(const StepParams P, const in
         const float4 v = s_fk[lane];
         o[0] = v.x; o[1] = v.y; o[2] = v.z;
     }
-    __syncthreads();
+    WAVE_SYNC();
     STAMP(6);
 
     // ================= stream the staged observation prefix out: 16 bytes per lane per store =================
@@ -793,7 +812,7 @@ __global__ __launch_bounds__(64, 5) void k_env_post(const StepParams P, const in
     }
     STAMP(7);
 #ifdef PARC_STAMPS
-    __syncthreads();
+    WAVE_SYNC();
     if (lane < 7 && P.stamp_out) P.stamp_out[(size_t)e * 8 + lane] = (unsigned)(s_stamp[lane + 1] - s_stamp[lane]);
     if (lane == 7 && P.stamp_out) P.stamp_out[(size_t)e * 8 + 7] = 0;
 #endif
@@ -1710,7 +1729,8 @@ extern "C" int parc_env_load_terrain(ParcEnv *e, const float *hf, int32_t X, int
         sp.tile_mul = mul;
     }
     const int stage_pad = (sp.off_tarc + 3) & ~3;
-    e->lds_bytes = sizeof(float) * (size_t)stage_pad + (e->cfg.report_tracking_error ? 2 * 16 * sizeof(float4) : 0);
+    e->lds_bytes = sizeof(float) * (size_t)stage_pad + (e->cfg.report_tracking_error ? 2 * 16 * sizeof(float4) : 0); // per wave of k_env_post
+    e->sp.lds_wave_floats = (int)(e->lds_bytes / sizeof(float));
     e->have_terrain = true;
     e->graph_dirty = true;
     return sync_params(e);
@@ -1781,16 +1801,17 @@ static bool wants_mirror(const ParcEnvBuffers &b) {
 static int launch_post(ParcEnv *e, int mode, const int64_t *ids, int count, hipStream_t st, const int *ids32 = nullptr,
                        const int *count_dev = nullptr, bool prep_done = false, unsigned long long *bump = nullptr) {
     if (count <= 0) return PARC_OK;
-    const int grid = count;
+    const int grid = (count + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK;
+    const size_t lds = e->lds_bytes * ENVS_PER_BLOCK;
     if (mode == MODE_STEP && e->cfg.enable_dynamics && e->use_wave) prep_done = true; // k_dynamics_wave wrote the prep records with the state
     if (!prep_done) hipLaunchKernelGGL(k_env_prep, dim3((count + 3) / 4), dim3(64), 0, st, e->sp, ids, ids32, count_dev, count);
     const bool mirror = wants_mirror(e->sp.buf);
     if (mode == MODE_STEP) {
-        if (mirror) hipLaunchKernelGGL((k_env_post<MODE_STEP, true>), dim3(grid), dim3(64), e->lds_bytes, st, e->sp, ids, ids32, count_dev, count, bump);
-        else hipLaunchKernelGGL((k_env_post<MODE_STEP, false>), dim3(grid), dim3(64), e->lds_bytes, st, e->sp, ids, ids32, count_dev, count, bump);
+        if (mirror) hipLaunchKernelGGL((k_env_post<MODE_STEP, true>), dim3(grid), dim3(64 * ENVS_PER_BLOCK), lds, st, e->sp, ids, ids32, count_dev, count, bump);
+        else hipLaunchKernelGGL((k_env_post<MODE_STEP, false>), dim3(grid), dim3(64 * ENVS_PER_BLOCK), lds, st, e->sp, ids, ids32, count_dev, count, bump);
     } else {
-        if (mirror) hipLaunchKernelGGL((k_env_post<MODE_OBS, true>), dim3(grid), dim3(64), e->lds_bytes, st, e->sp, ids, ids32, count_dev, count, bump);
-        else hipLaunchKernelGGL((k_env_post<MODE_OBS, false>), dim3(grid), dim3(64), e->lds_bytes, st, e->sp, ids, ids32, count_dev, count, bump);
+        if (mirror) hipLaunchKernelGGL((k_env_post<MODE_OBS, true>), dim3(grid), dim3(64 * ENVS_PER_BLOCK), lds, st, e->sp, ids, ids32, count_dev, count, bump);
+        else hipLaunchKernelGGL((k_env_post<MODE_OBS, false>), dim3(grid), dim3(64 * ENVS_PER_BLOCK), lds, st, e->sp, ids, ids32, count_dev, count, bump);
     }
 
     HIPCHK(hipGetLastError());
