@@ -269,6 +269,7 @@ __global__ __launch_bounds__(256, 5) void k_env_post(const StepParams P, const i
     __shared__ float4 s_refvel_all[ENVS_PER_BLOCK][12]; // record float4 #20..: root_vel, root_ang_vel, dof_vel
     __shared__ float s_refct_all[ENVS_PER_BLOCK][16];
     __shared__ float s_cfn_all[ENVS_PER_BLOCK][16];
+    __shared__ float s_sc_all[ENVS_PER_BLOCK][16];      // per-env scalars handed to the wave that forms the rewards (MODE_STEP)
 #ifdef PARC_STAMPS
     __shared__ unsigned long long s_stamp_all[ENVS_PER_BLOCK][16];
 #endif
@@ -348,16 +349,27 @@ __global__ __launch_bounds__(256, 5) void k_env_post(const StepParams P, const i
     const Q4 root_rot = mk4(crr[0], crr[1], crr[2], crr[3]);
     const float gx = root_pos.x + eox, gy = root_pos.y + eoy, gz = root_pos.z + eoz; // ig_parkour_env.py:522
 
-    // (c) reference motion: rows 1..1+S (row = pass*4 + lane/16), two 512-byte frame records per sample
+    // (c) reference motion: rows 1..1+S (row = pass*4 + lane/16), two 512-byte frame records per sample.  The frame pair and blend factor
+    // of a sample (motion_lib.py:425-438) are formed once, by lane (sample & 7): sample 0 = the reference at t, sample s = look-ahead
+    // target s; the row / contact / velocity lanes fetch theirs with a lane shuffle instead of evaluating the blend four times per lane.
+    Blend myb;
+    {
+        const int sid = lane & 7;
+        float t = mt;
+#pragma unroll
+        for (int q = 0; q < PARC_MAX_TAR_STEPS; ++q) t = (sid - 1 == q) ? mt + P.tstep[q] : t;
+        myb = frame_blend(meta, t);
+    }
+    const int last_frame = meta.start + meta.nframes - 1;
     float4 fA[2], fB[2];
     Blend bl[2];
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         const int r = p * 4 + (lane >> 4);
-        float t = mt;
-#pragma unroll
-        for (int q = 0; q < PARC_MAX_TAR_STEPS; ++q) t = (r - 2 == q) ? mt + P.tstep[q] : t;
-        bl[p] = frame_blend(meta, t);
+        const int src = max(r - 1, 0);
+        bl[p].b = __shfl(myb.b, src, 64);
+        bl[p].i0 = __shfl(myb.i0, src, 64);
+        bl[p].i1 = min(bl[p].i0 + 1, last_frame); // = frame_blend's i1
         fA[p] = make_float4(0.f, 0.f, 0.f, 1.f); fB[p] = fA[p];
         if (r >= 1 && r < 2 + S) {
             fA[p] = P.records[(size_t)bl[p].i0 * REC_F4 + qi];
@@ -368,18 +380,18 @@ __global__ __launch_bounds__(256, 5) void k_env_post(const StepParams P, const i
     float4 cA = make_float4(0.f, 0.f, 0.f, 0.f), cB = cA;
     float cblend = 0.f;
     const int nvel = 2 + (D + 3) / 4;
-    if (lane < 4 * (1 + S)) {
-        const int s = lane >> 2, c = lane & 3;
-        float t = mt;
-#pragma unroll
-        for (int q = 0; q < PARC_MAX_TAR_STEPS; ++q) t = (s - 1 == q) ? mt + P.tstep[q] : t;
-        const Blend b2 = frame_blend(meta, t);
-        cblend = b2.b;
-        cA = P.records[(size_t)b2.i0 * REC_F4 + REC_Q_CONTACT + c];
-        cB = P.records[(size_t)b2.i1 * REC_F4 + REC_Q_CONTACT + c];
-    } else if (lane >= 32 && lane < 32 + nvel) { // velocities come from frame idx0 un-interpolated (:103-109)
-        const Blend b2 = frame_blend(meta, mt);
-        cA = P.records[(size_t)b2.i0 * REC_F4 + REC_Q_VEL + (lane - 32)];
+    {
+        const int src = lane < 4 * (1 + S) ? lane >> 2 : 0;
+        const float b2b = __shfl(myb.b, src, 64);
+        const int b2i0 = __shfl(myb.i0, src, 64), b2i1 = min(b2i0 + 1, last_frame);
+        if (lane < 4 * (1 + S)) {
+            const int c = lane & 3;
+            cblend = b2b;
+            cA = P.records[(size_t)b2i0 * REC_F4 + REC_Q_CONTACT + c];
+            cB = P.records[(size_t)b2i1 * REC_F4 + REC_Q_CONTACT + c];
+        } else if (lane >= 32 && lane < 32 + nvel) { // velocities come from frame idx0 un-interpolated (:103-109)
+            cA = P.records[(size_t)b2i0 * REC_F4 + REC_Q_VEL + (lane - 32)];
+        }
     }
     // (e) terrain tile cells
     const int tr = P.tile_r, TW = 2 * tr + 1, ncell = tr >= 0 ? TW * TW : 0;
@@ -633,126 +645,161 @@ __global__ __launch_bounds__(256, 5) void k_env_post(const StepParams P, const i
     STAMP(5);
 
     if (MODE == MODE_STEP) {
-        WAVE_SYNC(); // s_cbp
-        // ---- reward terms, one per lane (mgdm_dm_util.py:270-333, 498-518).  Row layout of the two partial-sum registers:
-        //   va: row 0 = joint pose terms (lane J of row 0 carries the root rotation angle, not summed), row 2 = contact terms,
-        //       row 3 = key-body terms;  vb: rows 0..1 = dof velocity terms (and beyond, for D > 32).
-        float va = 0.f, vb = 0.f, dang = 0.f;
-        if (lane <= J) { // angle of ref (x) conj(char): joints on lanes < J, the root on lane J (slot 0 of both rows)
-            const int slot = lane < J ? 1 + lane : 0;
-            dang = quat_diff_angle(s_q[0][slot], s_q[1][slot]);
-            if (lane < J) va = T->joint_err_w[lane] * dang * dang;
-        }
-        if (lane < D) {
-            const float v = ((const float *)s_refvel)[8 + lane] - s_cdofv[lane];
-            vb = T->dof_err_w[lane] * v * v;
-        }
-        if (lane >= 48 && lane < 48 + K) { // key positions: simulator bodies vs reference FK (ig_parkour_env.py:987)
-            const int b = s_tab.key_ids[lane - 48];
-            const float4 kp = s_cbp[b], tk = s_fk[16 + b], trp = s_q[1][15];
-            const float dx = (tk.x - trp.x) - (kp.x - root_pos.x);
-            const float dy = (tk.y - trp.y) - (kp.y - root_pos.y);
-            const float dz = (tk.z - trp.z) - (kp.z - root_pos.z);
-            va = dx * dx + dy * dy + dz * dz;
-        }
-        if (lane >= 32 && lane < 32 + B) { // contact term
-            const int b = lane - 32;
-            const float tar = s_refct[b], f = s_cfn[b];
-            float cr = -(1.0f - tar) * f;
-            cr = cr + tar * f;
-            va = T->contact_w[b] * cr;
-        }
-        // ---- early termination (mgdm_dm_util.py:335-402) ----
-        bool bad = false;
-        if (lane >= 1 && lane < B) {
-            const float4 bp = s_cbp[lane], b0 = s_cbp[0], tp = s_fk[16 + lane], t0 = s_fk[16];
-            const float dx = (tp.x - t0.x) - (bp.x - b0.x);
-            const float dy = (tp.y - t0.y) - (bp.y - b0.y);
-            const float dz = (tp.z - t0.z) - (bp.z - b0.z);
-            const float lim = T->pose_term_dist[lane - 1];
-            bad = (dx * dx + dy * dy + dz * dz) > lim * lim;
-        }
-        const bool pose_fail_any = __ballot(bad) != 0ull;
-        // fall rule (contact_bodies != [], mgdm_dm_util.py:349-360): a contact-force component above 0.1 on a body that is not a contact body
-        // AND such a body lower than termination_height above the terrain under it (global xy = env-local + env offset, :147-152)
-        bool fallen = false;
-        if (P.fall_mask != 0u) { // uniform
-            bool fc = false, fh = false;
-            if (lane >= 32 && lane < 32 + B && !((P.fall_mask >> (lane - 32)) & 1u))
+        // ---- reward + done of the workgroup's four envs on ONE of its waves: 16 lanes per env (row j = env j, lane i of the row = one
+        // joint / body / dof / term).  Every sum, exponential and comparison below is one instruction stream for four envs instead of one
+        // per env on 1-16 of 64 lanes.  Each wave hands its per-env scalars over through s_sc; the quaternions, FK positions, body
+        // positions, reference velocities and contact terms are already in its LDS slice.  The owner rotates with the block index so
+        // that the extra work does not pile up on one SIMD.
+        {
+            float *sc = s_sc_all[wv];
+            bool fc = false; // fall rule, first half (mgdm_dm_util.py:349-360): a contact-force component above 0.1 on a non-contact body
+            if (P.fall_mask != 0u && lane >= 32 && lane < 32 + B && !((P.fall_mask >> (lane - 32)) & 1u))
                 fc = fabsf(aux0) > 0.1f || fabsf(aux1) > 0.1f || fabsf(aux2) > 0.1f;
-            if (lane < B && !((P.fall_mask >> lane) & 1u)) {
-                const float4 bp = s_cbp[lane];
-                const int ix = min(max(cell_index(bp.x + eox, P.min_x, P.dx), 0), P.X - 1), iy = min(max(cell_index(bp.y + eoy, P.min_y, P.dy), 0), P.Y - 1);
-                fh = bp.z < P.hf[(size_t)ix * P.Y + iy] + P.term_h;
+            const bool fcany = __ballot(fc) != 0ull;
+            if (lane == 30) { sc[5] = aux0; sc[6] = aux1; sc[7] = aux2; }
+            if (lane == 31) { sc[8] = aux0; sc[9] = aux1; sc[10] = aux2; }
+            if (lane == 0) {
+                sc[0] = time; sc[1] = mt; sc[2] = __int_as_float(ts); sc[3] = meta.length; sc[4] = __int_as_float(meta.loop);
+                sc[11] = fcany ? 1.f : 0.f; sc[12] = eox; sc[13] = eoy; sc[14] = __int_as_float(e);
             }
-            fallen = (__ballot(fc) != 0ull) && (__ballot(fh) != 0ull);
         }
-        const float root_rot_angle = lane_value(dang, J);
-        va = row_sum16(va); vb = row_sum16(vb);
-        const float pose_err = lane_value(va, 0), csum = lane_value(va, 32), key_err = lane_value(va, 48);
-        const float vel_err = (lane_value(vb, 0) + lane_value(vb, 16)) + (lane_value(vb, 32) + lane_value(vb, 48));
-
-        // scalar tail: the five exponentials run on five lanes, everything else is uniform; lane 0 stores
-        const float4 trp = s_q[1][15];
-        float rdx = trp.x - root_pos.x, rdy = trp.y - root_pos.y, rdz = trp.z - root_pos.z;
-        if (!P.track_root) { rdx = 0.f; rdy = 0.f; }
-        if (!P.track_root_h) rdz = 0.f;
-        const float root_pos_err = rdx * rdx + rdy * rdy + rdz * rdz;
-        const float4 tv = s_refvel[0], tav = s_refvel[1];
-        const float rvx = lane_value(aux0, 30), rvy = lane_value(aux1, 30), rvz = lane_value(aux2, 30);
-        const float rax = lane_value(aux0, 31), ray_ = lane_value(aux1, 31), raz = lane_value(aux2, 31);
-        const float rre = root_rot_angle * root_rot_angle;
-        float d0 = tv.x - rvx, d1 = tv.y - rvy, d2 = tv.z - rvz;
-        const float rve = d0 * d0 + d1 * d1 + d2 * d2;
-        d0 = tav.x - rax; d1 = tav.y - ray_; d2 = tav.z - raz;
-        const float rave = d0 * d0 + d1 * d1 + d2 * d2;
-        float earg = -0.25f * pose_err;
-        earg = lane == 1 ? -0.01f * vel_err : earg;
-        earg = lane == 2 ? -5.0f * (root_pos_err + 0.1f * rre) : earg;
-        earg = lane == 3 ? -1.0f * (rve + 0.1f * rave) : earg;
-        earg = lane == 4 ? -10.0f * key_err : earg;
-        const float eval = expf(earg);
-        const float pose_r = lane_value(eval, 0), vel_r = lane_value(eval, 1), root_pose_r = lane_value(eval, 2),
-                    root_vel_r = lane_value(eval, 3), key_pos_r = lane_value(eval, 4);
-        float rew = P.pose_w * pose_r + P.vel_w * vel_r + P.root_pos_w * root_pose_r + P.root_vel_w * root_vel_r + P.key_pos_w * key_pos_r;
-        const float contact_pen = csum / (float)B; // torch.mean over bodies (ig_parkour_env.py:1033)
-        rew = rew + contact_pen;
-        // done (compute_done + DeepMimicEnv.update_done dm_env.py:628-665)
-        int done = PARC_DONE_NULL;
-        if (time >= P.episode_length) done = PARC_DONE_TIME;
-        if (P.early_term) {
-            bool failed = fallen;
-            if (P.pose_term) {
-                bool pf = pose_fail_any;
-                if (P.track_root) {
-                    const float4 b0 = s_cbp[0], t0 = s_fk[16];
-                    const float ex = b0.x - t0.x, ey = b0.y - t0.y, ez = b0.z - t0.z;
-                    pf = pf || (ex * ex + ey * ey + ez * ez) > P.root_pos_term_sq;
-                    pf = pf || fabsf(root_rot_angle) > P.root_rot_term;
-                }
-                failed = failed || pf;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // the four waves' LDS slices are complete (waves of a short last block have left)
+        const int nact = min(ENVS_PER_BLOCK, count - (int)blockIdx.x * ENVS_PER_BLOCK);
+        int owner = blockIdx.x & (ENVS_PER_BLOCK - 1);
+        if (owner >= nact) owner = 0;
+        if (wv == owner) {
+            const int j = lane >> 4, i = lane & 15, rowbase = lane & 48;
+            const bool valid = j < nact;
+            const int jj = valid ? j : 0;
+            const float4 (*q)[16] = s_q_all[jj];
+            const float4 *fk = s_fk_all[jj];
+            const float4 *cbp = s_lq_all[jj][0];
+            const float *scj = s_sc_all[jj];
+            const float4 rp4 = q[0][15], trp = q[1][15];
+            // reward terms, one per lane (mgdm_dm_util.py:270-333, 498-518); every row sum is taken at the row's lane 0
+            float dang = 0.f, vpose = 0.f;
+            if (i <= J) { // angle of ref (x) conj(char): joints on lanes < J, the root on lane J (slot 0 of both rows)
+                const int slot = i < J ? 1 + i : 0;
+                dang = quat_diff_angle(q[0][slot], q[1][slot]);
+                if (i < J) vpose = T->joint_err_w[i] * dang * dang;
             }
-            if (!(time > 1e-5f)) failed = false;
-            if (failed) done = PARC_DONE_FAIL;
-        }
-        const bool motion_end = (mt >= meta.length) && (meta.loop != PARC_LOOP_WRAP);
-        unsigned char code = 0;
-        if (done != PARC_DONE_NULL || motion_end) code = (done == PARC_DONE_FAIL) ? 1 : 2;
-        if (motion_end) done = PARC_DONE_FAIL;
-        if (P.never_done) done = PARC_DONE_NULL; // ig_parkour_env.py:980: after update_done (the curriculum still sees the episode end)
-        if (lane == 0) {
-            P.buf.reward[e] = rew;
-            P.buf.done[e] = done;
-            P.ema_code[e] = code;
-            P.buf.timestep[e] = ts;
-            if (P.buf.time) P.buf.time[e] = time;
-        }
-        if (P.buf.reward_terms && lane < 7) {
-            const float vals[7] = {pose_r, vel_r, root_pose_r, root_vel_r, key_pos_r, contact_pen, rew};
-            float v = vals[0];
+            float vs[4] = {0.f, 0.f, 0.f, 0.f}; // dof velocity terms, 16 dofs per pass (the sums pair up as the four 16-lane rows of a wave would)
 #pragma unroll
-            for (int q = 1; q < 7; ++q) v = lane == q ? vals[q] : v;
-            P.buf.reward_terms[(size_t)lane * P.N + e] = v;
+            for (int pss = 0; pss < (PARC_MAX_DOFS + 15) / 16; ++pss) {
+                if (16 * pss < D) { // uniform
+                    const int d = 16 * pss + i;
+                    float v = 0.f;
+                    if (d < D) {
+                        const float dv = ((const float *)s_refvel_all[jj])[8 + d] - s_cdofv_all[jj][d];
+                        v = T->dof_err_w[d] * dv * dv;
+                    }
+                    vs[pss] = row_sum16(v);
+                }
+            }
+            float vkey = 0.f;
+            if (i < K) { // key positions: simulator bodies vs reference FK (ig_parkour_env.py:987)
+                const int b = s_tab.key_ids[i];
+                const float4 kp = cbp[b], tk = fk[16 + b];
+                const float dx = (tk.x - trp.x) - (kp.x - rp4.x);
+                const float dy = (tk.y - trp.y) - (kp.y - rp4.y);
+                const float dz = (tk.z - trp.z) - (kp.z - rp4.z);
+                vkey = dx * dx + dy * dy + dz * dz;
+            }
+            float vct = 0.f;
+            if (i < B) { // contact term
+                const float tar = s_refct_all[jj][i], f = s_cfn_all[jj][i];
+                float cr = -(1.0f - tar) * f;
+                cr = cr + tar * f;
+                vct = T->contact_w[i] * cr;
+            }
+            // ---- early termination (mgdm_dm_util.py:335-402) ----
+            bool bad = false;
+            if (i >= 1 && i < B) {
+                const float4 bp = cbp[i], b0 = cbp[0], tp = fk[16 + i], t0 = fk[16];
+                const float dx = (tp.x - t0.x) - (bp.x - b0.x);
+                const float dy = (tp.y - t0.y) - (bp.y - b0.y);
+                const float dz = (tp.z - t0.z) - (bp.z - b0.z);
+                const float lim = T->pose_term_dist[i - 1];
+                bad = (dx * dx + dy * dy + dz * dz) > lim * lim;
+            }
+            const bool pose_fail_any = ((unsigned)(__ballot(bad) >> rowbase) & 0xffffu) != 0u;
+            // fall rule, second half: a non-contact body lower than termination_height above the terrain under it (global xy = env-local
+            // + env offset, :147-152)
+            bool fallen = false;
+            if (P.fall_mask != 0u) { // uniform
+                bool fh = false;
+                if (i < B && !((P.fall_mask >> i) & 1u)) {
+                    const float4 bp = cbp[i];
+                    const int ix = min(max(cell_index(bp.x + scj[12], P.min_x, P.dx), 0), P.X - 1), iy = min(max(cell_index(bp.y + scj[13], P.min_y, P.dy), 0), P.Y - 1);
+                    fh = bp.z < P.hf[(size_t)ix * P.Y + iy] + P.term_h;
+                }
+                fallen = scj[11] != 0.f && ((unsigned)(__ballot(fh) >> rowbase) & 0xffffu) != 0u;
+            }
+            const float root_rot_angle = __shfl(dang, rowbase + J, 64);
+            const float pose_err = __shfl(row_sum16(vpose), rowbase, 64), csum = __shfl(row_sum16(vct), rowbase, 64), key_err = __shfl(row_sum16(vkey), rowbase, 64);
+            const float vel_err = __shfl((vs[0] + vs[1]) + (vs[2] + vs[3]), rowbase, 64);
+
+            // per-env tail: every lane of a row carries its env's values; the five exponentials run on lanes 0..4 of the row
+            const float time_j = scj[0], mt_j = scj[1], mlen_j = scj[3];
+            const int ts_j = __float_as_int(scj[2]), mloop_j = __float_as_int(scj[4]), e_j = __float_as_int(scj[14]);
+            float rdx = trp.x - rp4.x, rdy = trp.y - rp4.y, rdz = trp.z - rp4.z;
+            if (!P.track_root) { rdx = 0.f; rdy = 0.f; }
+            if (!P.track_root_h) rdz = 0.f;
+            const float root_pos_err = rdx * rdx + rdy * rdy + rdz * rdz;
+            const float4 tv = s_refvel_all[jj][0], tav = s_refvel_all[jj][1];
+            const float rre = root_rot_angle * root_rot_angle;
+            float d0 = tv.x - scj[5], d1 = tv.y - scj[6], d2 = tv.z - scj[7];
+            const float rve = d0 * d0 + d1 * d1 + d2 * d2;
+            d0 = tav.x - scj[8]; d1 = tav.y - scj[9]; d2 = tav.z - scj[10];
+            const float rave = d0 * d0 + d1 * d1 + d2 * d2;
+            float earg = -0.25f * pose_err;
+            earg = i == 1 ? -0.01f * vel_err : earg;
+            earg = i == 2 ? -5.0f * (root_pos_err + 0.1f * rre) : earg;
+            earg = i == 3 ? -1.0f * (rve + 0.1f * rave) : earg;
+            earg = i == 4 ? -10.0f * key_err : earg;
+            const float eval = expf(earg);
+            const float pose_r = __shfl(eval, rowbase, 64), vel_r = __shfl(eval, rowbase + 1, 64), root_pose_r = __shfl(eval, rowbase + 2, 64),
+                        root_vel_r = __shfl(eval, rowbase + 3, 64), key_pos_r = __shfl(eval, rowbase + 4, 64);
+            float rew = P.pose_w * pose_r + P.vel_w * vel_r + P.root_pos_w * root_pose_r + P.root_vel_w * root_vel_r + P.key_pos_w * key_pos_r;
+            const float contact_pen = csum / (float)B; // torch.mean over bodies (ig_parkour_env.py:1033)
+            rew = rew + contact_pen;
+            // done (compute_done + DeepMimicEnv.update_done dm_env.py:628-665)
+            int done = PARC_DONE_NULL;
+            if (time_j >= P.episode_length) done = PARC_DONE_TIME;
+            if (P.early_term) {
+                bool failed = fallen;
+                if (P.pose_term) {
+                    bool pf = pose_fail_any;
+                    if (P.track_root) {
+                        const float4 b0 = cbp[0], t0 = fk[16];
+                        const float ex = b0.x - t0.x, ey = b0.y - t0.y, ez = b0.z - t0.z;
+                        pf = pf || (ex * ex + ey * ey + ez * ez) > P.root_pos_term_sq;
+                        pf = pf || fabsf(root_rot_angle) > P.root_rot_term;
+                    }
+                    failed = failed || pf;
+                }
+                if (!(time_j > 1e-5f)) failed = false;
+                if (failed) done = PARC_DONE_FAIL;
+            }
+            const bool motion_end = (mt_j >= mlen_j) && (mloop_j != PARC_LOOP_WRAP);
+            unsigned char code = 0;
+            if (done != PARC_DONE_NULL || motion_end) code = (done == PARC_DONE_FAIL) ? 1 : 2;
+            if (motion_end) done = PARC_DONE_FAIL;
+            if (P.never_done) done = PARC_DONE_NULL; // ig_parkour_env.py:980: after update_done (the curriculum still sees the episode end)
+            if (valid && i == 0) {
+                P.buf.reward[e_j] = rew;
+                P.buf.done[e_j] = done;
+                P.ema_code[e_j] = code;
+                P.buf.timestep[e_j] = ts_j;
+                if (P.buf.time) P.buf.time[e_j] = time_j;
+            }
+            if (P.buf.reward_terms && valid && i < 7) {
+                const float vals[7] = {pose_r, vel_r, root_pose_r, root_vel_r, key_pos_r, contact_pen, rew};
+                float v = vals[0];
+#pragma unroll
+                for (int qq = 1; qq < 7; ++qq) v = i == qq ? vals[qq] : v;
+                P.buf.reward_terms[(size_t)i * P.N + e_j] = v;
+            }
         }
 
         // optional outputs: ref body positions / dof positions, tracking error
@@ -768,7 +815,11 @@ __global__ __launch_bounds__(256, 5) void k_env_post(const StepParams P, const i
             const int nd = ty == PARC_JOINT_HINGE ? 1 : (ty == PARC_JOINT_SPHERICAL ? 3 : 0);
             for (int k = 0; k < nd; ++k) P.buf.ref_dof_pos[(size_t)e * D + T->h.dof_idx[lane] + k] = out3[k];
         }
-        if (MIRROR && P.tracking && P.buf.tracking_error) { // mgdm_dm_util.py:521-553
+        if (MIRROR && P.tracking && P.buf.tracking_error) { // mgdm_dm_util.py:521-553 (per wave: an optional output, off in training)
+            const float4 trp = s_q[1][15], tv = s_refvel[0], tav = s_refvel[1];
+            const float root_rot_angle = quat_diff_angle(s_q[0][0], s_q[1][0]);
+            const float rvx = lane_value(aux0, 30), rvy = lane_value(aux1, 30), rvz = lane_value(aux2, 30);
+            const float rax = lane_value(aux0, 31), ray_ = lane_value(aux1, 31), raz = lane_value(aux2, 31);
             float e_rot = 0.f, e_pos = 0.f, e_dv = 0.f;
             if (lane < B) {
                 e_rot = fabsf(quat_diff_angle(s_br[0][lane], s_br[1][lane]));
