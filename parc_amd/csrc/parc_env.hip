@@ -139,11 +139,14 @@ __device__ __forceinline__ void joint_rot_to_dof(int type, const float *axis4, Q
 // the residual x - d*q0 is exact in one fma, q = RN(q0 + r*rd) is the correctly rounded quotient (Markstein's
 // reciprocal-with-correction division; checked exhaustively against x/d on the CPU by tests/test_host_cpu.py for the
 // grid spacings in use).  3 instructions instead of the ~13 of the general sequence; used by the 441-ray loop.
-__device__ __forceinline__ int cell_index_rcp(float p, float mn, float d, float rd) {
+__device__ __forceinline__ float cell_float_rcp(float p, float mn, float d, float rd) { // the cell index while still a float
     const float x = p - mn;
     const float q0 = x * rd;
     const float r = fmaf(-d, q0, x);
-    float f = rintf(fmaf(r, rd, q0));
+    return rintf(fmaf(r, rd, q0));
+}
+__device__ __forceinline__ int cell_index_rcp(float p, float mn, float d, float rd) {
+    float f = cell_float_rcp(p, mn, d, rd);
     f = fminf(fmaxf(f, -1.0e9f), 1.0e9f);
     return (int)f;
 }
@@ -395,7 +398,8 @@ __global__ __launch_bounds__(256, 5) void k_env_post(const StepParams P, const i
     }
     // (e) terrain tile cells
     const int tr = P.tile_r, TW = 2 * tr + 1, ncell = tr >= 0 ? TW * TW : 0;
-    const int ox = cell_index(gx, P.min_x, P.dx) - tr, oy = cell_index(gy, P.min_y, P.dy) - tr;
+    // (the origin is kept within +-2^22 cells so that it and the tile bounds are exact as floats: the ray loop clamps in float)
+    const int ox = min(max(cell_index(gx, P.min_x, P.dx) - tr, -(1 << 22)), 1 << 22), oy = min(max(cell_index(gy, P.min_y, P.dy) - tr, -(1 << 22)), 1 << 22);
     float tilev[5];
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
@@ -443,6 +447,7 @@ __global__ __launch_bounds__(256, 5) void k_env_post(const StepParams P, const i
 #pragma unroll
                 for (int i = 0; i < RAY_UNROLL; ++i) { const int r = base + lane + 64 * i; rayp[i] = r < P.R ? ((const float2 *)P.ray_points)[r] : make_float2(0.f, 0.f); }
             }
+            const float tlox = (float)ox, thix = (float)(ox + TW - 1), tloy = (float)oy, thiy = (float)(oy + TW - 1);
             if (tr >= 0) { // the tile radius covers the whole fan by construction (parc_env_load_terrain): clamp, no fallback
                 // every tile index is formed before the first store: a later use of a loaded ray point would have to wait for
                 // the stores issued in between (one counter orders loads and stores).  Lanes past the end of the fan carry the
@@ -454,8 +459,10 @@ __global__ __launch_bounds__(256, 5) void k_env_post(const StepParams P, const i
                     if (base + 64 * i < P.R) { // uniform
                         const float px = (rayp[i].x * ch - rayp[i].y * sh) + gx; // rotate_2d_vec torch_util.py:651
                         const float py = (rayp[i].x * sh + rayp[i].y * ch) + gy;
-                        const int ix = cell_index_rcp(px, P.min_x, P.dx, P.rdx), iy = cell_index_rcp(py, P.min_y, P.dy, P.rdy);
-                        const int a = min(max(ix - ox, 0), TW - 1), bq = min(max(iy - oy, 0), TW - 1);
+                        // nearest cell (cell_index_rcp), clamped to the tile while still a float: the bounds are small integers, so
+                        // clamp-then-convert equals convert-then-clamp and the guard against a wild float comes for free
+                        const int a = (int)fminf(fmaxf(cell_float_rcp(px, P.min_x, P.dx, P.rdx), tlox), thix) - ox;
+                        const int bq = (int)fminf(fmaxf(cell_float_rcp(py, P.min_y, P.dy, P.rdy), tloy), thiy) - oy;
                         tix[i] = a * TW + bq;
                     }
                     asm volatile("" : "+v"(tix[i])); // keep the index arithmetic here (not sunk below the stores)
