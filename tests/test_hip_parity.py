@@ -222,7 +222,9 @@ def test_env_reset_vs_reference_golden(genv):
 # mirror False = the instantiation bench.py and the learner run (k_env_post<MODE, false>: no optional ref_* / ray_hfs / tracking-error
 # outputs bound); True = the one the golden-vector tests use
 @pytest.mark.parametrize("mirror", [True, False])
-@pytest.mark.parametrize("n", [1, 100, 4096, 16384])  # 1 and 100: ragged (not a multiple of the 64-env blocks)
+# 1 and 100: ragged (not a multiple of the 64-env blocks of the dynamics); 13 and 1023: a short last workgroup of k_env_post (four envs
+# per workgroup, the rewards on the wave (block & 3) -- here a wave that has no env, so ownership falls back to wave 0)
+@pytest.mark.parametrize("n", [1, 13, 100, 1023, 4096, 16384])
 def test_env_step_vs_oracle_large(tmp_path, oracle, orc_char, n, mirror):
     """Same seeded state through the HIP step and the CPU oracle at cfg-2/cfg-3 env counts (from-FK bodies)."""
     import torch
