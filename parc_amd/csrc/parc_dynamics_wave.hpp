@@ -721,13 +721,13 @@ __device__ __forceinline__ void wv_store_joint(const DynModel &M, const WaveTabl
 __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__restrict__ Mp, const WaveTables *__restrict__ Wp, DynTerrain T,
                                                           ParcEnvBuffers buf, const float *__restrict__ action,
                                                           const float *__restrict__ env_off_all, float *__restrict__ root_shadow,
-                                                          float4 *__restrict__ prep, int N) {
+                                                          float4 *__restrict__ prep, int N, int epb) {
     extern __shared__ float smem[];
     const DynModel &M = *Mp;
     const WaveTables &W = *Wp;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int e = blockIdx.x * 64 + lane;
+    const int e = blockIdx.x * epb + lane; // epb = envs per block: 64, or 32 (half-filled waves) when that is what it takes to put a block on every CU
     const bool env_ok = e < N;
     const int ec = env_ok ? e : N - 1; // clamp for address safety; lanes past N compute on a copy and store nothing
     const float dt = M.dt;
@@ -746,6 +746,7 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
     // it reads the record); [15] = "a wait of this block timed out"
     int *s_flag = reinterpret_cast<int *>(smem + WV_OFF_FLAG);
     if (threadIdx.x < 16) s_flag[threadIdx.x] = 0; // published before the first barrier below
+    if (lane >= epb) return; // lanes without an env leave (the wave goes on with the others; barriers and flags are per wave)
 
     const float *dp = buf.char_dof_pos + (size_t)D_ * ec, *dv = buf.char_dof_vel + (size_t)D_ * ec, *ac = action + (size_t)D_ * ec;
     WvBody limb[WV_MAXLEN], trunk[WV_MAXLEN];
