@@ -26,7 +26,7 @@ names = {"headline": "bench", "kinematic_65536": "bench_kinematic_65536", "cfg3"
 for k, v in names.items():
     json.dump(json.load(open(f"gpurun_out/bench_set_{bset}/{k}.json")), open(f"profiles/{tag}_{v}.json", "w"), indent=1)
 if ks:
-    f = glob.glob(f"gpurun_out/kstats_{ks}/**/*kernel_stats.csv", recursive=True)[0]
+    f = max(glob.glob(f"gpurun_out/kstats_{ks}/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime)  # the directory keeps earlier runs
     rows = list(csv.reader(open(f)))
     csv.writer(open(f"profiles/{tag}_shard_8192_kernel_stats.csv", "w")).writerows([rows[0]] + [r for r in rows[1:] if any(k in r[0] for k in ("k_", "rocclr"))])
 d = json.load(open(f"profiles/{tag}_pmc_dynamics.json"))
