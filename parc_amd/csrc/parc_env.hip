@@ -890,10 +890,10 @@ __device__ __forceinline__ int nonzero_bytes(unsigned v) {
 
 // Block b owns envs [1024 b, 1024 b + 1024).  Its base offset = number of finished envs before it, which it
 // counts itself from the (1 byte per env) code array: no atomics in the step kernel, no second launch.
-__global__ __launch_bounds__(1024) void k_done_scatter(const unsigned char *__restrict__ ema_code, const int *__restrict__ motion_ids,
-                                                       int N, int *done_list, int *done_key, int *reset_count, int never_done) {
+__device__ __forceinline__ void done_scatter_block(const unsigned char *__restrict__ ema_code, const int *__restrict__ motion_ids, int N, int *done_list,
+                                                   int *done_key, int *reset_count, int never_done, int b, int nblocks) {
     __shared__ int s_base, s_wave[16];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid == 0) s_base = 0;
     __syncthreads();
     {
@@ -919,10 +919,14 @@ __global__ __launch_bounds__(1024) void k_done_scatter(const unsigned char *__re
         done_list[pos] = e;
         done_key[pos] = (motion_ids[e] << 1) | (code == 1 ? 1 : 0);
     }
-    if (b == (int)gridDim.x - 1 && tid == 0) {
+    if (b == nblocks - 1 && tid == 0) {
         reset_count[0] = s_base + total;                   // entries of the list: the fail-rate EMA walks all of them
         reset_count[1] = never_done ? 0 : s_base + total;  // envs parc_env_reset_done resets (never_done: flags are NULL, nobody)
     }
+}
+__global__ __launch_bounds__(1024) void k_done_scatter(const unsigned char *__restrict__ ema_code, const int *__restrict__ motion_ids,
+                                                       int N, int *done_list, int *done_key, int *reset_count, int never_done) {
+    done_scatter_block(ema_code, motion_ids, N, done_list, done_key, reset_count, never_done, blockIdx.x, gridDim.x);
 }
 
 // One 1024-thread block per motion.  The block sweeps the env-ordered list and compacts (stable, by rank) the addends of its
@@ -931,14 +935,39 @@ __global__ __launch_bounds__(1024) void k_done_scatter(const unsigned char *__re
 // dm_env.py:651-658, bit for bit).  The chain is inherently serial (each update rounds): only its two dependent VALU
 // operations per entry stay on it, the addends arrive four at a time from LDS.
 #define EMA_CAP 8192
-__global__ __launch_bounds__(1024) void k_fail_rate_ema(const int *__restrict__ done_key, const int *__restrict__ reset_count,
-                                                       float *fail_rates, int M, float w) {
+// the chain itself, on one thread: f <- f*keep + addend over `n` buffered addends (eight LDS reads in flight: only the first one's latency is exposed)
+__device__ __forceinline__ float ema_chain(float f, const float *s_add, int n, float keep) {
+    int i4 = 0;
+    const float4 *a4 = (const float4 *)s_add;
+    for (; i4 + 32 <= n; i4 += 32) {
+        float4 q[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) q[j] = a4[(i4 >> 2) + j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            f = f * keep; f = f + q[j].x;
+            f = f * keep; f = f + q[j].y;
+            f = f * keep; f = f + q[j].z;
+            f = f * keep; f = f + q[j].w;
+        }
+    }
+    for (; i4 + 4 <= n; i4 += 4) {
+        const float4 a = a4[i4 >> 2];
+        f = f * keep; f = f + a.x;
+        f = f * keep; f = f + a.y;
+        f = f * keep; f = f + a.z;
+        f = f * keep; f = f + a.w;
+    }
+    for (; i4 < n; ++i4) { f = f * keep; f = f + s_add[i4]; }
+    return f;
+}
+// KeyAt(i) = (motion << 1) | fail bit of entry i of the env-ordered sequence, or a negative value for "no entry"; k = its length
+template <class KeyAt>
+__device__ __forceinline__ void fail_rate_ema_block(KeyAt key_at, int k, float *fail_rates, int m, float w) {
     __shared__ __align__(16) float s_add[EMA_CAP];
     __shared__ int s_wtot[16];
     __shared__ float s_f;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = blockIdx.x;
-    const int k = *reset_count;
-    if (k == 0 || m >= M) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const float keep = (float)(1.0 - (double)w);
     if (tid == 0) s_f = fail_rates[m];
     __syncthreads();
@@ -946,8 +975,8 @@ __global__ __launch_bounds__(1024) void k_fail_rate_ema(const int *__restrict__ 
     bool any = false;
     for (int tile = 0; tile < k; tile += 1024) {
         const int i = tile + tid;
-        const int v = i < k ? done_key[i] : -2;
-        const bool match = (v >> 1) == m;
+        const int v = i < k ? key_at(i) : -2;
+        const bool match = v >= 0 && (v >> 1) == m;
         const unsigned long long mask = __ballot(match);
         if (lane == 0) s_wtot[wv] = __popcll(mask);
         __syncthreads();
@@ -960,29 +989,7 @@ __global__ __launch_bounds__(1024) void k_fail_rate_ema(const int *__restrict__ 
         const bool last = tile + 1024 >= k;
         if (nmatch + 1024 > EMA_CAP || (last && nmatch > 0)) { // flush: sequential chain over the buffered addends
             if (tid == 0) {
-                float f = s_f;
-                int i4 = 0;
-                const float4 *a4 = (const float4 *)s_add;
-                for (; i4 + 32 <= nmatch; i4 += 32) { // eight LDS reads in flight: only the first one's latency is exposed
-                    float4 q[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) q[j] = a4[(i4 >> 2) + j];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        f = f * keep; f = f + q[j].x;
-                        f = f * keep; f = f + q[j].y;
-                        f = f * keep; f = f + q[j].z;
-                        f = f * keep; f = f + q[j].w;
-                    }
-                }
-                for (; i4 + 4 <= nmatch; i4 += 4) {
-                    const float4 a = a4[i4 >> 2];
-                    f = f * keep; f = f + a.x;
-                    f = f * keep; f = f + a.y;
-                    f = f * keep; f = f + a.z;
-                    f = f * keep; f = f + a.w;
-                }
-                for (; i4 < nmatch; ++i4) { f = f * keep; f = f + s_add[i4]; }
+                const float f = ema_chain(s_f, s_add, nmatch, keep);
                 s_f = f;
             }
             nmatch = 0;
@@ -990,6 +997,72 @@ __global__ __launch_bounds__(1024) void k_fail_rate_ema(const int *__restrict__ 
         }
     }
     if (tid == 0 && any) fail_rates[m] = s_f;
+}
+// The same chain straight from the step kernel's per-env codes (1 byte per env: 0 = not finished, 1 = FAIL, 2 = other) for shards of up to
+// CURRICULUM_ONE_LAUNCH_MAX envs: every thread takes 8 consecutive envs (one 8-byte load; finished envs are few, so their motion ids are
+// conditional loads), a block-wide exclusive scan of the per-thread match counts gives each its place in env order, 8 192 envs per pass.
+__device__ __forceinline__ void fail_rate_ema_raw_block(const unsigned char *__restrict__ ema_code, const int *__restrict__ motion_ids, int N,
+                                                        float *fail_rates, int m, float w) {
+    __shared__ __align__(16) float s_add[EMA_CAP];
+    __shared__ int s_wtot[16];
+    __shared__ float s_f;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float keep = (float)(1.0 - (double)w);
+    if (tid == 0) s_f = fail_rates[m];
+    bool any = false;
+    for (int base = 0; base < N; base += EMA_CAP) { // N is a multiple of 8 on this path (launch_curriculum)
+        const int e0 = base + 8 * tid;
+        unsigned long long codes = 0ull;
+        if (e0 < N) codes = *(const unsigned long long *)(ema_code + e0);
+        unsigned matchbits = 0u, failbits = 0u;
+        if (codes) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned c = (unsigned)(codes >> (8 * j)) & 0xffu;
+                if (c && motion_ids[e0 + j] == m) { matchbits |= 1u << j; if (c == 1u) failbits |= 1u << j; }
+            }
+        }
+        const int cnt = __popc(matchbits);
+        int incl = cnt; // inclusive scan within the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int u = __shfl_up(incl, d, 64); if (lane >= d) incl += u; }
+        __syncthreads(); // s_f / the previous pass's buffer are settled
+        if (lane == 63) s_wtot[wv] = incl;
+        __syncthreads();
+        int woff = 0, total = 0;
+        for (int q = 0; q < 16; ++q) { const int c = s_wtot[q]; if (q < wv) woff += c; total += c; }
+        int pos = woff + incl - cnt;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (matchbits & (1u << j)) s_add[pos++] = (failbits & (1u << j)) ? w : 0.0f;
+        __syncthreads();
+        if (total > 0) { // uniform
+            any = true;
+            if (tid == 0) s_f = ema_chain(s_f, s_add, total, keep);
+        }
+    }
+    __syncthreads();
+    if (tid == 0 && any) fail_rates[m] = s_f;
+}
+__global__ __launch_bounds__(1024) void k_fail_rate_ema(const int *__restrict__ done_key, const int *__restrict__ reset_count,
+                                                       float *fail_rates, int M, float w) {
+    const int k = *reset_count, m = blockIdx.x;
+    if (k == 0 || m >= M) return;
+    fail_rate_ema_block([&](int i) { return done_key[i]; }, k, fail_rates, m, w);
+}
+// Both of the above as ONE launch, for shards of up to CURRICULUM_ONE_LAUNCH_MAX envs (what a GPU of an 8-GPU job runs): blocks [0, nchunks) compact the finished envs
+// (the reset list), blocks nchunks.. apply the EMA of motion m -- reading the step kernel's per-env codes directly instead of the compacted
+// list, so that no block waits for another.  Same entries in the same (env) order: bit-identical to the two launches.
+#define CURRICULUM_ONE_LAUNCH_MAX 8192 // measured: -1.6 us per step at 8 192 envs, +1.6 us at 16 384 (two passes of the scan)
+__global__ __launch_bounds__(1024) void k_curriculum_small(const unsigned char *__restrict__ ema_code, const int *__restrict__ motion_ids, int N,
+                                                          int *done_list, int *done_key, int *reset_count, int never_done, int nchunks,
+                                                          float *fail_rates, int M, float w) {
+    if ((int)blockIdx.x < nchunks) {
+        done_scatter_block(ema_code, motion_ids, N, done_list, done_key, reset_count, never_done, blockIdx.x, nchunks);
+    } else {
+        const int m = (int)blockIdx.x - nchunks;
+        if (m >= M) return;
+        fail_rate_ema_raw_block(ema_code, motion_ids, N, fail_rates, m, w);
+    }
 }
 
 // Large libraries (thousands of motions, a handful of finished envs each): one block per motion sweeping the whole list is
@@ -1482,6 +1555,7 @@ struct ParcEnv {
     hipGraphExec_t graph_exec = nullptr;           // parc_env_step_reset_graph
     bool graph_dirty = true;
     bool force_ema_leader = false;                 // test switch PARC_EMA_LEADER=1: the large-library EMA path on a small library
+    bool force_two_launch_curriculum = false;      // test switch PARC_CURRICULUM_TWO_LAUNCHES=1: k_done_scatter + k_fail_rate_ema on a small shard
     int grid_waves = 0;
     int num_cus = 256;
     size_t lds_bytes = 0;
@@ -1661,6 +1735,7 @@ extern "C" int parc_env_create(const ParcEnvConfig *cfg, ParcEnv **out) {
         }
     }
     e->force_ema_leader = getenv("PARC_EMA_LEADER") != nullptr;
+    e->force_two_launch_curriculum = getenv("PARC_CURRICULUM_TWO_LAUNCHES") != nullptr;
     for (auto &ev : e->ev) (void)hipEventCreate(&ev);
     sp.tables = e->d_tab; sp.ray_points = e->d_ray; sp.env_offsets = e->d_env_off;
     sp.ema_code = e->d_ema; sp.prep = e->d_prep;
@@ -1844,6 +1919,12 @@ static int launch_dynamics(ParcEnv *e, const float *action_dev, hipStream_t st) 
 
 static int launch_curriculum(ParcEnv *e, hipStream_t st) {
     e->done_list_fresh = true;
+    if (e->M <= 64 && !e->force_ema_leader && e->N <= CURRICULUM_ONE_LAUNCH_MAX && (e->N & 7) == 0 && !e->force_two_launch_curriculum) {
+        hipLaunchKernelGGL(k_curriculum_small, dim3(e->nchunks + e->M), dim3(1024), 0, st, e->d_ema, e->sp.buf.motion_ids, e->N, e->d_done_list,
+                           e->d_done_key, e->d_reset_count, e->sp.never_done, e->nchunks, e->d_fail, e->M, e->cfg.fail_rate_ema_weight);
+        HIPCHK(hipGetLastError());
+        return PARC_OK;
+    }
     hipLaunchKernelGGL(k_done_scatter, dim3(e->nchunks), dim3(1024), 0, st, e->d_ema, e->sp.buf.motion_ids, e->N, e->d_done_list,
                        e->d_done_key, e->d_reset_count, e->sp.never_done);
     if (e->M <= 64 && !e->force_ema_leader) {

@@ -254,10 +254,12 @@ def test_never_done_and_consumed_reset_list(tmp_path):
     assert (fr_nd < 1.0).any()   # the EMA ran although no flag was raised
 
 
-def test_large_library_ema_path_equals_the_per_motion_chain(tmp_path, monkeypatch):
-    """Libraries of thousands of motions update the fail rates with one leader thread per motion that finished an env
-    (k_ema_first / k_ema_leader) instead of one block per motion; both apply the reference's sequential chain
-    (dm_env.py:646-660) in env order, so the tables must be bit-identical."""
+def test_curriculum_launch_variants_are_bit_identical(tmp_path, monkeypatch):
+    """Three ways to the same fail-rate table and reset list: (a) shards of up to 8 192 envs with a small library: compaction of the
+    finished envs and the per-motion EMA as ONE launch (the EMA blocks read the step kernel's per-env codes themselves); (b) the two
+    launches larger env counts use (k_done_scatter, then k_fail_rate_ema on the compacted list); (c) libraries of thousands of motions:
+    one leader thread per motion that finished an env (k_ema_first / k_ema_leader).  All apply the reference's sequential chain
+    (dm_env.py:646-660) in env order, so the tables -- and the resets drawn from them -- must be bit-identical."""
     import torch
     from gpu_helpers import default_config, write_motion_yaml
     from helpers import CLIPS4
@@ -266,11 +268,12 @@ def test_large_library_ema_path_equals_the_per_motion_chain(tmp_path, monkeypatc
     cfg = default_config()
     cfg["env"]["dm"]["motion_file"] = write_motion_yaml(tmp_path, CLIPS4, [1, 1, 1, 1])
     envs = []
-    for leader in (False, True):
-        if leader:
-            monkeypatch.setenv("PARC_EMA_LEADER", "1")
+    for switch in (None, "PARC_CURRICULUM_TWO_LAUNCHES", "PARC_EMA_LEADER"):
+        if switch:
+            monkeypatch.setenv(switch, "1")
         envs.append(HipParkourEnv(cfg, n, "cuda:0", False, seed=4))
-        monkeypatch.delenv("PARC_EMA_LEADER", raising=False)
+        if switch:
+            monkeypatch.delenv(switch, raising=False)
     for env in envs:
         env.reset()
     g = torch.Generator(device="cuda:0"); g.manual_seed(9)
@@ -279,7 +282,10 @@ def test_large_library_ema_path_equals_the_per_motion_chain(tmp_path, monkeypatc
         for env in envs:
             env._char_root_pos += drift
             env.step(None); env.reset_done()
-        fa, fb = envs[0].get_fail_rates().numpy(), envs[1].get_fail_rates().numpy()
-        assert np.array_equal(fa, fb), (s, fa, fb)
-    assert (fa < 1.0).all() and torch.equal(envs[0]._motion_ids, envs[1]._motion_ids)
-
+        fa = envs[0].get_fail_rates().numpy()
+        for other in envs[1:]:
+            assert np.array_equal(fa, other.get_fail_rates().numpy()), (s, fa, other.get_fail_rates().numpy())
+    assert (fa < 1.0).all()
+    for other in envs[1:]:
+        assert torch.equal(envs[0]._motion_ids, other._motion_ids) and torch.equal(envs[0]._timestep_buf, other._timestep_buf)
+        assert torch.equal(envs[0]._obs_buf, other._obs_buf)
