@@ -251,7 +251,9 @@ __device__ __forceinline__ float lane_value(float v, int l) { return __int_as_fl
 // MIRROR = false: none of the optional outputs (the ref_* mirrors of the reference's tensors, ray_hfs, tracking_error) is bound --
 // the training configuration.  Their pointers and null checks then leave the kernel (20+ SGPRs: the kernel is at the SGPR limit and every
 // scalar spilled to a VGPR lane comes back as a VALU instruction).
-template <int MODE, bool MIRROR>
+// LOCALROOT = the config's `track_root: false`: the reward compares root rotation, root velocities and key positions in each character's
+// own heading frame (convert_to_local, mgdm_dm_util.py:247-267).  An instantiation of its own so that the default one carries none of it.
+template <int MODE, bool MIRROR, bool LOCALROOT = false>
 __global__ __launch_bounds__(256, 5) void k_env_post(const StepParams P, const int64_t *__restrict__ env_ids,
                                                  const int *__restrict__ env_ids32, const int *__restrict__ count_dev, int count,
                                                  unsigned long long *bump_calls) {
@@ -685,9 +687,20 @@ __global__ __launch_bounds__(256, 5) void k_env_post(const StepParams P, const i
             const float4 rp4 = q[0][15], trp = q[1][15];
             // reward terms, one per lane (mgdm_dm_util.py:270-333, 498-518); every row sum is taken at the row's lane 0
             float dang = 0.f, vpose = 0.f;
+            Q4 hinv_c = mk4(0.f, 0.f, 0.f, 1.f), hinv_r = hinv_c; // LOCALROOT: inverse heading of the character / of the reference
+            if (LOCALROOT) {
+                hinv_c = heading_quat_inv(calc_heading(q[0][0]));
+                hinv_r = heading_quat_inv(calc_heading(q[1][0]));
+            }
             if (i <= J) { // angle of ref (x) conj(char): joints on lanes < J, the root on lane J (slot 0 of both rows)
                 const int slot = i < J ? 1 + i : 0;
-                dang = quat_diff_angle(q[0][slot], q[1][slot]);
+                if (LOCALROOT) {
+                    Q4 qa = q[0][slot], qb = q[1][slot];
+                    if (i == J) { qa = quat_mul(hinv_c, qa); qb = quat_mul(hinv_r, qb); }
+                    dang = quat_diff_angle(qa, qb);
+                } else {
+                    dang = quat_diff_angle(q[0][slot], q[1][slot]);
+                }
                 if (i < J) vpose = T->joint_err_w[i] * dang * dang;
             }
             float vs[4] = {0.f, 0.f, 0.f, 0.f}; // dof velocity terms, 16 dofs per pass (the sums pair up as the four 16-lane rows of a wave would)
@@ -707,10 +720,17 @@ __global__ __launch_bounds__(256, 5) void k_env_post(const StepParams P, const i
             if (i < K) { // key positions: simulator bodies vs reference FK (ig_parkour_env.py:987)
                 const int b = s_tab.key_ids[i];
                 const float4 kp = cbp[b], tk = fk[16 + b];
-                const float dx = (tk.x - trp.x) - (kp.x - rp4.x);
-                const float dy = (tk.y - trp.y) - (kp.y - rp4.y);
-                const float dz = (tk.z - trp.z) - (kp.z - rp4.z);
-                vkey = dx * dx + dy * dy + dz * dz;
+                if (LOCALROOT) {
+                    const V3 kt = quat_rotate(hinv_r, mk3(tk.x - trp.x, tk.y - trp.y, tk.z - trp.z));
+                    const V3 kc = quat_rotate(hinv_c, mk3(kp.x - rp4.x, kp.y - rp4.y, kp.z - rp4.z));
+                    const float dx = kt.x - kc.x, dy = kt.y - kc.y, dz = kt.z - kc.z;
+                    vkey = dx * dx + dy * dy + dz * dz;
+                } else {
+                    const float dx = (tk.x - trp.x) - (kp.x - rp4.x);
+                    const float dy = (tk.y - trp.y) - (kp.y - rp4.y);
+                    const float dz = (tk.z - trp.z) - (kp.z - rp4.z);
+                    vkey = dx * dx + dy * dy + dz * dz;
+                }
             }
             float vct = 0.f;
             if (i < B) { // contact term
@@ -755,10 +775,20 @@ __global__ __launch_bounds__(256, 5) void k_env_post(const StepParams P, const i
             const float root_pos_err = rdx * rdx + rdy * rdy + rdz * rdz;
             const float4 tv = s_refvel_all[jj][0], tav = s_refvel_all[jj][1];
             const float rre = root_rot_angle * root_rot_angle;
-            float d0 = tv.x - scj[5], d1 = tv.y - scj[6], d2 = tv.z - scj[7];
-            const float rve = d0 * d0 + d1 * d1 + d2 * d2;
-            d0 = tav.x - scj[8]; d1 = tav.y - scj[9]; d2 = tav.z - scj[10];
-            const float rave = d0 * d0 + d1 * d1 + d2 * d2;
+            float rve, rave;
+            if (LOCALROOT) {
+                const V3 tv3 = quat_rotate(hinv_r, mk3(tv.x, tv.y, tv.z)), tav3 = quat_rotate(hinv_r, mk3(tav.x, tav.y, tav.z));
+                const V3 rv3 = quat_rotate(hinv_c, mk3(scj[5], scj[6], scj[7])), rav3 = quat_rotate(hinv_c, mk3(scj[8], scj[9], scj[10]));
+                float d0 = tv3.x - rv3.x, d1 = tv3.y - rv3.y, d2 = tv3.z - rv3.z;
+                rve = d0 * d0 + d1 * d1 + d2 * d2;
+                d0 = tav3.x - rav3.x; d1 = tav3.y - rav3.y; d2 = tav3.z - rav3.z;
+                rave = d0 * d0 + d1 * d1 + d2 * d2;
+            } else {
+                float d0 = tv.x - scj[5], d1 = tv.y - scj[6], d2 = tv.z - scj[7];
+                rve = d0 * d0 + d1 * d1 + d2 * d2;
+                d0 = tav.x - scj[8]; d1 = tav.y - scj[9]; d2 = tav.z - scj[10];
+                rave = d0 * d0 + d1 * d1 + d2 * d2;
+            }
             float earg = -0.25f * pose_err;
             earg = i == 1 ? -0.01f * vel_err : earg;
             earg = i == 2 ? -5.0f * (root_pos_err + 0.1f * rre) : earg;
@@ -1665,7 +1695,6 @@ extern "C" int parc_env_create(const ParcEnvConfig *cfg, ParcEnv **out) {
     sp.early_term = cfg->enable_early_termination; sp.pose_term = cfg->pose_termination; sp.track_root = cfg->track_root;
     sp.track_root_h = cfg->track_root_h; sp.tracking = cfg->report_tracking_error; sp.body_pos_from_fk = cfg->body_pos_from_fk;
     sp.fall_mask = cfg->contact_body_mask & ((1u << B) - 1u); sp.term_h = cfg->termination_height;
-    if (!cfg->track_root) { delete e; return fail(PARC_ERR_INVALID, "track_root=false is not supported"); }
 
     auto up = [&](void **dst, const void *src, size_t bytes) -> hipError_t {
         hipError_t r = hipMalloc(dst, bytes);
@@ -1952,7 +1981,10 @@ static int launch_post(ParcEnv *e, int mode, const int64_t *ids, int count, hipS
     if (mode == MODE_STEP && e->cfg.enable_dynamics && e->use_wave) prep_done = true; // k_dynamics_wave wrote the prep records with the state
     if (!prep_done) hipLaunchKernelGGL(k_env_prep, dim3((count + 3) / 4), dim3(64), 0, st, e->sp, ids, ids32, count_dev, count);
     const bool mirror = wants_mirror(e->sp.buf);
-    if (mode == MODE_STEP) {
+    if (mode == MODE_STEP && !e->sp.track_root) { // track_root: false -- the reward in the characters' heading frames
+        if (mirror) hipLaunchKernelGGL((k_env_post<MODE_STEP, true, true>), dim3(grid), dim3(64 * ENVS_PER_BLOCK), lds, st, e->sp, ids, ids32, count_dev, count, bump);
+        else hipLaunchKernelGGL((k_env_post<MODE_STEP, false, true>), dim3(grid), dim3(64 * ENVS_PER_BLOCK), lds, st, e->sp, ids, ids32, count_dev, count, bump);
+    } else if (mode == MODE_STEP) {
         if (mirror) hipLaunchKernelGGL((k_env_post<MODE_STEP, true>), dim3(grid), dim3(64 * ENVS_PER_BLOCK), lds, st, e->sp, ids, ids32, count_dev, count, bump);
         else hipLaunchKernelGGL((k_env_post<MODE_STEP, false>), dim3(grid), dim3(64 * ENVS_PER_BLOCK), lds, st, e->sp, ids, ids32, count_dev, count, bump);
     } else {

@@ -580,6 +580,40 @@ def gen_env_step_fall(m):
     print("fall fixture: done histogram", np.bincount(d, minlength=4), "rows kind 3 failed:", d[3::4])
 
 
+def gen_env_step_local_root(m):
+    """`track_root: False` (mgdm_dm_util.py:294-310, 386): the reward drops the horizontal root position error and compares root rotation,
+    root velocities and key positions in each character's own heading frame (convert_to_local :247-267); compute_done skips the root
+    position / rotation termination.  Same scene and reset as env_step.npz; one step on injected state, a few rows turned far off the
+    reference heading so that the two frames differ."""
+    cfg = env_config()
+    cfg["env"]["track_root"] = False
+    n = 64
+    env, dm = build_harness(m, CLIPS, n, cfg)
+    assert env._track_root is False
+    g = torch.Generator().manual_seed(23)
+    torch.manual_seed(77)
+    dm.reset(torch.arange(n))
+    env._refresh_sim_tensors()
+    env._update_observations(torch.arange(n))
+    env._timestep_buf[:] = torch.randint(1, 40, (n,), generator=g, dtype=torch.int32)
+    inject_state(env, dm, m, g, noise=0.02, big_noise_rows=(6, 7, 8, 9))
+    # rows 16..31: the character turned about z by up to +-2.5 rad and displaced by metres: with track_root the episode would end
+    ang = (torch.rand(16, generator=g) * 5.0 - 2.5)
+    dq = torch.stack([torch.zeros(16), torch.zeros(16), torch.sin(0.5 * ang), torch.cos(0.5 * ang)], dim=-1)
+    env._char_root_rot[16:32] = tu.quat_mul(dq, env._char_root_rot[16:32])
+    shift = torch.zeros(n, 3); shift[24:40, 0:2] = torch.rand(16, 2, generator=g) * 4.0 - 2.0
+    env._char_root_pos[:] = env._char_root_pos + shift
+    bp, br = m.forward_kinematics(env._char_root_pos, env._char_root_rot, m.dof_to_rot(env._char_dof_pos))
+    env._char_rigid_body_pos[:] = bp
+    env._char_rigid_body_rot[:] = br
+    arrs = {"track_root": np.int32(0)}
+    arrs.update(state_dict(env, dm, "in_"))
+    ig_env.IGEnv._post_physics_step(env)
+    arrs.update(out_dict(env, dm, "out_"))
+    save("env_step_local_root", **arrs)
+    print("local-root fixture: done histogram", np.bincount(npy(env._done_buf), minlength=4), "reward range", float(env._reward_buf.min()), float(env._reward_buf.max()))
+
+
 def gen_done_table():
     g = torch.Generator().manual_seed(5)
     n = 128
@@ -617,3 +651,4 @@ if __name__ == "__main__":
     gen_done_table()
     gen_env_step(model)
     gen_env_step_fall(model)
+    gen_env_step_local_root(model)

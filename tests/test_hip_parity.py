@@ -190,6 +190,37 @@ def test_fall_termination_with_contact_bodies_vs_reference_golden(tmp_path):
     assert (outs[False] != outs[True]).sum() >= 8     # with contact_bodies = [] nobody falls (some of the 16 rows also reach their motion end)
 
 
+def test_env_step_without_root_tracking_vs_reference_golden(tmp_path):
+    """`track_root: False` (off the default config; rejected with an error until round 3): the reward in the characters' own heading
+    frames (convert_to_local, mgdm_dm_util.py:247-267, :294-310) and compute_done without the root terms (:386), against the reference's
+    own `_post_physics_step` (env_step_local_root.npz: sixteen characters turned by up to 2.5 rad, sixteen displaced by metres).  Runs the
+    `k_env_post<STEP, *, LOCALROOT>` instantiations; the default config keeps running the ones without that code."""
+    from gpu_helpers import default_config, write_motion_yaml, inject, to_np, GOLDEN_WEIGHTS
+    from parc_amd.envs.hip_parkour_env import HipParkourEnv
+    g, g0 = golden("env_step_local_root"), golden("env_step")
+    rew = {}
+    for track in (False, True):
+        for mirror in ((True, False) if not track else (True,)):
+            cfg = default_config()
+            cfg["env"]["dm"]["motion_file"] = write_motion_yaml(tmp_path, [str(c) for c in g0["clips"]], GOLDEN_WEIGHTS)
+            cfg["env"]["hip"]["body_pos_from_fk"] = False
+            cfg["env"]["track_root"] = track
+            env = HipParkourEnv(cfg, 64, "cuda:0", False, mirror_ref_state=mirror)
+            inject(env, g, "in_")
+            env.step(None)
+            rew[(track, mirror)] = to_np(env._reward_buf).copy()
+            if not track:
+                assert np.array_equal(to_np(env._done_buf), g["out_done"])
+                close(to_np(env._reward_buf), g["out_reward"], what="reward")
+                close(env.get_fail_rates().numpy(), g["out_fail_rates"], tol=0, what="fail_rates")
+                err = np.abs(to_np(env._obs_buf) - g["out_obs"])
+                ray_bad = np.abs(to_np(env._obs_buf)[:, 871:] - g["out_obs"][:, 871:]) > TOL
+                err[:, 871:][ray_bad] = 0
+                assert ray_bad.mean() < 2e-4 and err.max() <= TOL
+    assert np.array_equal(rew[(False, True)], rew[(False, False)])             # both instantiations, bit for bit
+    assert np.abs(rew[(True, True)][16:40] - rew[(False, True)][16:40]).max() > 0.05   # the switch matters on this state
+
+
 def test_env_reset_vs_reference_golden(genv):
     import torch
     from gpu_helpers import to_np

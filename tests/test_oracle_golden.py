@@ -289,3 +289,35 @@ def test_fall_termination_with_contact_bodies_vs_reference(oracle, orc_char):
     oracle.env_post_physics_step(orc_char, sc["lib"], sc["terrain"], cfg0, st)
     oracle.env_update_curriculum(sc["lib"], cfg0, st)
     assert (st["done"] != g["out_done"]).sum() >= 8      # (some of the sixteen fall rows also reach their motion end)
+
+
+def test_env_step_without_root_tracking_vs_reference_golden(oracle, orc_char):
+    """`track_root: False` (off the default config): the reward drops the horizontal root position error and compares root rotation, root
+    velocities and key positions in each character's OWN heading frame (convert_to_local, mgdm_dm_util.py:247-267, :294-310);
+    compute_done skips the root position / rotation termination (:386).  env_step_local_root.npz is the reference's own
+    `_post_physics_step` on a state where sixteen characters are turned by up to 2.5 rad and sixteen displaced by metres."""
+    from helpers import build_oracle_scene, default_cfg, load_state_into
+    g = golden("env_step_local_root")
+    g0 = golden("env_step")
+    sc = build_oracle_scene(oracle, orc_char, g0)
+    n = g0["env_offsets"].shape[0]
+    st = sc["state"]
+    out = {}
+    for track in (False, True):
+        cfg = default_cfg(oracle, n, g0["ray_points"], g0["env_offsets"], g0["motion_offsets"], track_root=track)
+        load_state_into(st, g, "in_")
+        oracle.env_post_physics_step(orc_char, sc["lib"], sc["terrain"], cfg, st)
+        oracle.env_update_curriculum(sc["lib"], cfg, st)
+        out[track] = (st["reward"].copy(), st["done"].copy())
+        if not track:
+            assert np.array_equal(st["done"], g["out_done"])
+            np.testing.assert_allclose(st["reward"], g["out_reward"], atol=1e-5)
+            for k_o, k_g in [("r_root_pos_r", "out_r_root_pos_r"), ("r_root_vel_r", "out_r_root_vel_r"), ("r_key_pos_r", "out_r_key_pos_r")]:
+                if k_o in st:
+                    np.testing.assert_allclose(st[k_o], g[k_g], atol=1e-5)
+            np.testing.assert_allclose(st["obs"], g["out_obs"], atol=1e-5)
+            np.testing.assert_array_equal(st["fail_rates"], g["out_fail_rates"])
+    # the switch matters on this state: rewards of the turned / displaced rows differ, and with root tracking more episodes end
+    assert np.abs(out[True][0][16:40] - out[False][0][16:40]).max() > 0.05
+    assert (out[True][1] != 0).sum() > (out[False][1] != 0).sum()
+
