@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PARC_ABI_VERSION 3
+#define PARC_ABI_VERSION 4
 #define PARC_MAX_BODIES 16   /* 15 quats + root position share one 16-lane group */
 #define PARC_MAX_DOFS 40     /* dof velocities live in floats [88,128) of a 128-float frame record */
 #define PARC_MAX_TAR_STEPS 6 /* 2 + steps skeletons <= 8 lane groups of 8 */
@@ -133,6 +133,9 @@ typedef struct {
      * above 0.1 and some other body is lower than termination_height above the terrain under it (RefCharEnv.update_done :147-152). */
     uint32_t contact_body_mask;
     float termination_height;                /* ig_parkour_env.py:63 */
+    /* `global_obs` (ig_parkour_env.py:83; false by default): compute_char_obs (ig_char_env.py:586-589, :603) and compute_tar_obs
+     * (mgdm_dm_util.py:417) leave root rotation, root velocities, root / key offsets in the global frame. */
+    int32_t global_obs;
 } ParcEnvConfig;
 
 /* Motion clips as MotionLib._load_motion_file receives them (motion_lib.py:255-401); the library

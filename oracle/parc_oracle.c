@@ -622,20 +622,28 @@ static void compute_obs1(const OrcChar *c, const OrcMotionLib *lib, const OrcEnv
     dof_to_rot1(c, s->char_dof_pos + (size_t)D * e, jr);           /* :865 */
     fk1(c, root_pos, root_rot, jr, body_pos, NULL);                 /* :868 */
 
-    /* compute_char_obs ig_char_env.py:582-627 (global_obs False, root_height_obs False) */
+    /* compute_char_obs ig_char_env.py:582-627 (root_height_obs False); global_obs: the raw root rotation / velocities / key offsets */
+    const int gl = cfg->global_obs;
     float hinv[4], lr[4];
     calc_heading_quat_inv(root_rot, hinv);
-    quat_mul(hinv, root_rot, lr);
-    quat_to_tan_norm(lr, obs + 0);
-    quat_rotate(hinv, s->char_root_vel + 3 * e, obs + 6);
-    quat_rotate(hinv, s->char_root_ang_vel + 3 * e, obs + 9);
+    if (gl) {
+        quat_to_tan_norm(root_rot, obs + 0);
+        memcpy(obs + 6, s->char_root_vel + 3 * e, 3 * sizeof(float));
+        memcpy(obs + 9, s->char_root_ang_vel + 3 * e, 3 * sizeof(float));
+    } else {
+        quat_mul(hinv, root_rot, lr);
+        quat_to_tan_norm(lr, obs + 0);
+        quat_rotate(hinv, s->char_root_vel + 3 * e, obs + 6);
+        quat_rotate(hinv, s->char_root_ang_vel + 3 * e, obs + 9);
+    }
     for (int j = 0; j < J; ++j) quat_to_tan_norm(jr + 4 * j, obs + 12 + 6 * j);
     memcpy(obs + 12 + 6 * J, s->char_dof_vel + (size_t)D * e, (size_t)D * sizeof(float));
     for (int k = 0; k < K; ++k) {
         float rel[3];
         int b = cfg->key_body_ids[k];
         for (int a = 0; a < 3; ++a) rel[a] = body_pos[3 * b + a] - root_pos[a];
-        quat_rotate(hinv, rel, obs + 12 + 6 * J + D + 3 * k);
+        if (gl) memcpy(obs + 12 + 6 * J + D + 3 * k, rel, sizeof(rel));
+        else quat_rotate(hinv, rel, obs + 12 + 6 * J + D + 3 * k);
     }
 
     /* DeepMimicEnv.compute_tar_obs dm_env.py:594-626 + fetch_tar_obs_data mgdm_dm_util.py:221 + compute_tar_obs :405 */
@@ -652,17 +660,26 @@ static void compute_obs1(const OrcChar *c, const OrcMotionLib *lib, const OrcEnv
         float *o = tar + (size_t)si * tar_w;
         float rpo[3], rpl[3], lrr[4];
         for (int a = 0; a < 3; ++a) rpo[a] = trp[a] - root_pos[a];
-        quat_rotate(hinv, rpo, rpl);
-        o[0] = rpl[0]; o[1] = rpl[1]; o[2] = rpl[2];
-        quat_mul(hinv, trr, lrr);
-        quat_to_tan_norm(lrr, o + 3);
+        if (gl) { /* mgdm_dm_util.py:417: nothing is turned into the heading frame, and the key offsets stay relative to the target root */
+            o[0] = rpo[0]; o[1] = rpo[1]; o[2] = rpo[2];
+            quat_to_tan_norm(trr, o + 3);
+        } else {
+            quat_rotate(hinv, rpo, rpl);
+            o[0] = rpl[0]; o[1] = rpl[1]; o[2] = rpl[2];
+            quat_mul(hinv, trr, lrr);
+            quat_to_tan_norm(lrr, o + 3);
+        }
         for (int j = 0; j < J; ++j) quat_to_tan_norm(tjr + 4 * j, o + 9 + 6 * j);
         for (int k = 0; k < K; ++k) {
             int b = cfg->key_body_ids[k];
             float rel[3], rl[3];
             for (int a = 0; a < 3; ++a) rel[a] = tbp[3 * b + a] - trp[a];
-            quat_rotate(hinv, rel, rl);
-            for (int a = 0; a < 3; ++a) o[9 + 6 * J + 3 * k + a] = rl[a] + rpl[a];
+            if (gl) {
+                for (int a = 0; a < 3; ++a) o[9 + 6 * J + 3 * k + a] = rel[a];
+            } else {
+                quat_rotate(hinv, rel, rl);
+                for (int a = 0; a < 3; ++a) o[9 + 6 * J + 3 * k + a] = rl[a] + rpl[a];
+            }
         }
     }
     /* char contacts ig_parkour_env.py:655-662 */

@@ -253,7 +253,9 @@ __device__ __forceinline__ float lane_value(float v, int l) { return __int_as_fl
 // scalar spilled to a VGPR lane comes back as a VALU instruction).
 // LOCALROOT = the config's `track_root: false`: the reward compares root rotation, root velocities and key positions in each character's
 // own heading frame (convert_to_local, mgdm_dm_util.py:247-267).  An instantiation of its own so that the default one carries none of it.
-template <int MODE, bool MIRROR, bool LOCALROOT = false>
+// GLOBALOBS = the config's `global_obs: true`: the character and target observations stay in the global frame (no heading rotation; the
+// targets' key offsets are not shifted by the root offset).  Instantiated with MIRROR = true only (off the default path).
+template <int MODE, bool MIRROR, bool LOCALROOT = false, bool GLOBALOBS = false>
 __global__ __launch_bounds__(256, 5) void k_env_post(const StepParams P, const int64_t *__restrict__ env_ids,
                                                  const int *__restrict__ env_ids32, const int *__restrict__ count_dev, int count,
                                                  unsigned long long *bump_calls) {
@@ -424,7 +426,7 @@ __global__ __launch_bounds__(256, 5) void k_env_post(const StepParams P, const i
         s_obs[P.off_dofvel + lane] = dofv;
     }
     if (lane == 30 || lane == 31) { // root velocities in the heading frame (ig_char_env.py:593-597)
-        const V3 r = quat_rotate(hinv, mk3(aux0, aux1, aux2));
+        const V3 r = GLOBALOBS ? mk3(aux0, aux1, aux2) : quat_rotate(hinv, mk3(aux0, aux1, aux2));
         const int o = lane == 30 ? 6 : 9;
         s_obs[o + 0] = r.x; s_obs[o + 1] = r.y; s_obs[o + 2] = r.z;
     }
@@ -552,14 +554,15 @@ __global__ __launch_bounds__(256, 5) void k_env_post(const StepParams P, const i
             } else { // observation pieces (ig_char_env.py:582, mgdm_dm_util.py:405)
                 const int base = r == 0 ? 0 : P.off_tar + (r - 2) * P.tar_w;
                 if (i < B) {
-                    const Q4 qq = i == 0 ? quat_mul(hinv, res) : res;
+                    const Q4 qq = (i == 0 && !GLOBALOBS) ? quat_mul(hinv, res) : res;
                     float tn[6];
                     quat_to_tan_norm(qq, tn);
                     const int o = r == 0 ? (i == 0 ? 0 : 12 + 6 * (i - 1)) : base + 3 + 6 * i;
 #pragma unroll
                     for (int c = 0; c < 6; ++c) s_obs[o + c] = tn[c];
                 } else if (i == 15 && r >= 2) {
-                    const V3 rpo = quat_rotate(hinv, mk3(res.x - root_pos.x, res.y - root_pos.y, res.z - root_pos.z));
+                    const V3 rpd = mk3(res.x - root_pos.x, res.y - root_pos.y, res.z - root_pos.z);
+                    const V3 rpo = GLOBALOBS ? rpd : quat_rotate(hinv, rpd);
                     s_obs[base + 0] = rpo.x; s_obs[base + 1] = rpo.y; s_obs[base + 2] = rpo.z;
                 }
             }
@@ -639,15 +642,21 @@ __global__ __launch_bounds__(256, 5) void k_env_post(const StepParams P, const i
         if (kk < K) {
             if (row == 0) {
                 const float4 kp = s_fk[s_tab.key_ids[kk]];
-                const V3 rl = quat_rotate(hinv, mk3(kp.x - root_pos.x, kp.y - root_pos.y, kp.z - root_pos.z));
+                const V3 rd = mk3(kp.x - root_pos.x, kp.y - root_pos.y, kp.z - root_pos.z);
+                const V3 rl = GLOBALOBS ? rd : quat_rotate(hinv, rd);
                 const int o = P.off_key + 3 * kk;
                 s_obs[o] = rl.x; s_obs[o + 1] = rl.y; s_obs[o + 2] = rl.z;
             } else {
                 const int r = row + 1;
                 const float4 kp = s_fk[32 + (r - 2) * 8 + s_tab.key_slot[s_tab.key_ids[kk]]], trp = s_q[r][15];
-                const V3 rl = quat_rotate(hinv, mk3(kp.x - trp.x, kp.y - trp.y, kp.z - trp.z));
+                const V3 rd = mk3(kp.x - trp.x, kp.y - trp.y, kp.z - trp.z);
                 const int tb = P.off_tar + (r - 2) * P.tar_w, o = tb + 3 + 6 * B + 3 * kk; // [tb, tb + 3): the row's root offset, staged by the row phase
-                s_obs[o] = rl.x + s_obs[tb]; s_obs[o + 1] = rl.y + s_obs[tb + 1]; s_obs[o + 2] = rl.z + s_obs[tb + 2];
+                if (GLOBALOBS) { // mgdm_dm_util.py:417: global key offsets are not shifted by the root offset
+                    s_obs[o] = rd.x; s_obs[o + 1] = rd.y; s_obs[o + 2] = rd.z;
+                } else {
+                    const V3 rl = quat_rotate(hinv, rd);
+                    s_obs[o] = rl.x + s_obs[tb]; s_obs[o + 1] = rl.y + s_obs[tb + 1]; s_obs[o + 2] = rl.z + s_obs[tb + 2];
+                }
             }
         }
     }
@@ -1992,7 +2001,11 @@ static int launch_post(ParcEnv *e, int mode, const int64_t *ids, int count, hipS
     if (mode == MODE_STEP && e->cfg.enable_dynamics && e->use_wave) prep_done = true; // k_dynamics_wave wrote the prep records with the state
     if (!prep_done) hipLaunchKernelGGL(k_env_prep, dim3((count + 3) / 4), dim3(64), 0, st, e->sp, ids, ids32, count_dev, count);
     const bool mirror = wants_mirror(e->sp.buf);
-    if (mode == MODE_STEP && !e->sp.track_root) { // track_root: false -- the reward in the characters' heading frames
+    if (e->cfg.global_obs) { // global_obs: true -- instantiated for the general (MIRROR) form only
+        if (mode == MODE_STEP && !e->sp.track_root) hipLaunchKernelGGL((k_env_post<MODE_STEP, true, true, true>), dim3(grid), dim3(64 * ENVS_PER_BLOCK), lds, st, e->sp, ids, ids32, count_dev, count, bump);
+        else if (mode == MODE_STEP) hipLaunchKernelGGL((k_env_post<MODE_STEP, true, false, true>), dim3(grid), dim3(64 * ENVS_PER_BLOCK), lds, st, e->sp, ids, ids32, count_dev, count, bump);
+        else hipLaunchKernelGGL((k_env_post<MODE_OBS, true, false, true>), dim3(grid), dim3(64 * ENVS_PER_BLOCK), lds, st, e->sp, ids, ids32, count_dev, count, bump);
+    } else if (mode == MODE_STEP && !e->sp.track_root) { // track_root: false -- the reward in the characters' heading frames
         if (mirror) hipLaunchKernelGGL((k_env_post<MODE_STEP, true, true>), dim3(grid), dim3(64 * ENVS_PER_BLOCK), lds, st, e->sp, ids, ids32, count_dev, count, bump);
         else hipLaunchKernelGGL((k_env_post<MODE_STEP, false, true>), dim3(grid), dim3(64 * ENVS_PER_BLOCK), lds, st, e->sp, ids, ids32, count_dev, count, bump);
     } else if (mode == MODE_STEP) {
@@ -2474,7 +2487,7 @@ extern "C" const char *parc_env_dynamics_kernel(ParcEnv *e) {
 
 extern "C" const char *parc_env_post_kernel(ParcEnv *e) {
     if (!e || !e->bound) return "";
-    return wants_mirror(e->sp.buf) ? "k_env_post<MODE,true>" : "k_env_post<MODE,false>";
+    return (wants_mirror(e->sp.buf) || e->cfg.global_obs) ? "k_env_post<MODE,true>" : "k_env_post<MODE,false>";
 }
 
 #ifdef PARC_STAMPS

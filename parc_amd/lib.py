@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # PARC_ENV_LIB: developer override used to A/B kernel builds; the shipped library is the in-tree one
 LIB_PATH = os.environ.get("PARC_ENV_LIB") or os.path.join(_HERE, "libparc_env.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_BODIES, MAX_DOFS, MAX_TAR_STEPS, MAX_KEY, MAX_FK_PATHS, MAX_FK_DEPTH, MAX_GEOMS = 16, 40, 6, 8, 8, 8, 24
 
 f32p = C.POINTER(C.c_float)
@@ -58,7 +58,8 @@ class ParcEnvConfig(C.Structure):
                 ("rand_root_pos_offset_scale", C.c_float), ("rand_reset", C.c_int32), ("demo_mode", C.c_int32),
                 ("env_offsets_host", f32p), ("action_low", C.c_float * MAX_DOFS), ("action_high", C.c_float * MAX_DOFS),
                 ("body_pos_from_fk", C.c_int32), ("enable_dynamics", C.c_int32), ("dynamics", ParcDynamicsParams),
-                ("seed", C.c_uint64), ("contact_body_mask", C.c_uint32), ("termination_height", C.c_float)]
+                ("seed", C.c_uint64), ("contact_body_mask", C.c_uint32), ("termination_height", C.c_float),
+                ("global_obs", C.c_int32)]
 
 
 class ParcMotionClips(C.Structure):

@@ -614,6 +614,31 @@ def gen_env_step_local_root(m):
     print("local-root fixture: done histogram", np.bincount(npy(env._done_buf), minlength=4), "reward range", float(env._reward_buf.min()), float(env._reward_buf.max()))
 
 
+def gen_env_step_global_obs(m):
+    """`global_obs: True` (ig_parkour_env.py:83): compute_char_obs (ig_char_env.py:586-589, :603) keeps the root rotation, the root
+    velocities and the key-body offsets in the global frame; compute_tar_obs (mgdm_dm_util.py:417) keeps the targets' root offset, root
+    rotation and key offsets global and does NOT add the root offset to the key offsets.  Same scene and reset as env_step.npz; the reset
+    observation and one step on injected state."""
+    cfg = env_config()
+    cfg["env"]["global_obs"] = True
+    n = 64
+    env, dm = build_harness(m, CLIPS, n, cfg)
+    assert env._global_obs is True
+    g = torch.Generator().manual_seed(31)
+    torch.manual_seed(99)
+    dm.reset(torch.arange(n))
+    env._refresh_sim_tensors()
+    env._update_observations(torch.arange(n))
+    arrs = {"global_obs": np.int32(1), "reset_obs": npy(env._obs_buf)}
+    arrs.update(state_dict(env, dm, "reset_"))
+    env._timestep_buf[:] = torch.randint(1, 40, (n,), generator=g, dtype=torch.int32)
+    inject_state(env, dm, m, g, noise=0.02, big_noise_rows=(6, 7, 8, 9))
+    arrs.update(state_dict(env, dm, "in_"))
+    ig_env.IGEnv._post_physics_step(env)
+    arrs.update(out_dict(env, dm, "out_"))
+    save("env_step_global_obs", **arrs)
+
+
 def gen_done_table():
     g = torch.Generator().manual_seed(5)
     n = 128
@@ -652,3 +677,4 @@ if __name__ == "__main__":
     gen_env_step(model)
     gen_env_step_fall(model)
     gen_env_step_local_root(model)
+    gen_env_step_global_obs(model)

@@ -68,7 +68,7 @@ def test_library_loaded_is_in_tree(genv):
     from parc_amd import lib as L
     assert L.LIB_PATH.endswith("parc_amd/libparc_env.so")
     from parc_amd import lib as L2
-    assert genv[0]._lib.parc_abi_version() == L2.ABI_VERSION == 3
+    assert genv[0]._lib.parc_abi_version() == L2.ABI_VERSION == 4
 
 
 def test_kin_ops_vs_golden(genv):
@@ -219,6 +219,45 @@ def test_env_step_without_root_tracking_vs_reference_golden(tmp_path):
                 assert ray_bad.mean() < 2e-4 and err.max() <= TOL
     assert np.array_equal(rew[(False, True)], rew[(False, False)])             # both instantiations, bit for bit
     assert np.abs(rew[(True, True)][16:40] - rew[(False, True)][16:40]).max() > 0.05   # the switch matters on this state
+
+
+def test_env_step_with_global_observations_vs_reference_golden(tmp_path):
+    """`global_obs: True` (off the default config; rejected with an error until round 3): root rotation, root velocities, root / key
+    offsets of the character and of the look-ahead targets stay in the global frame (compute_char_obs ig_char_env.py:586-589, :603;
+    compute_tar_obs mgdm_dm_util.py:417), against the reference's own `_post_physics_step` and reset observation
+    (env_step_global_obs.npz).  Runs the `k_env_post<*, true, *, GLOBALOBS>` instantiations."""
+    import torch
+    from gpu_helpers import default_config, write_motion_yaml, inject, to_np, GOLDEN_WEIGHTS
+    from parc_amd.envs.hip_parkour_env import HipParkourEnv
+    g, g0 = golden("env_step_global_obs"), golden("env_step")
+    obs = {}
+    for gl in (True, False):
+        cfg = default_config()
+        cfg["env"]["dm"]["motion_file"] = write_motion_yaml(tmp_path, [str(c) for c in g0["clips"]], GOLDEN_WEIGHTS)
+        cfg["env"]["hip"]["body_pos_from_fk"] = False
+        cfg["env"]["global_obs"] = gl
+        env = HipParkourEnv(cfg, 64, "cuda:0", False, mirror_ref_state=False)
+        assert env._lib.parc_env_post_kernel(env._handle).decode() == ("k_env_post<MODE,true>" if gl else "k_env_post<MODE,false>")
+        if gl:  # the observation pass on the reference's reset state (MODE_OBS instantiation)
+            inject(env, g, "reset_")
+            env._compute_obs()
+            torch.cuda.synchronize()
+            err = np.abs(to_np(env._obs_buf) - g["reset_obs"])
+            ray_bad = np.abs(to_np(env._obs_buf)[:, 871:] - g["reset_obs"][:, 871:]) > TOL
+            err[:, 871:][ray_bad] = 0
+            assert ray_bad.mean() < 2e-4 and err.max() <= TOL, err.max()
+        inject(env, g, "in_")
+        env.step(None)
+        obs[gl] = to_np(env._obs_buf).copy()
+        if gl:
+            assert np.array_equal(to_np(env._done_buf), g["out_done"])
+            close(to_np(env._reward_buf), g["out_reward"], what="reward")
+            err = np.abs(obs[gl] - g["out_obs"])
+            ray_bad = np.abs(obs[gl][:, 871:] - g["out_obs"][:, 871:]) > TOL
+            err[:, 871:][ray_bad] = 0
+            assert ray_bad.mean() < 2e-4 and err.max() <= TOL, err.max()
+    d = np.abs(obs[True] - obs[False])
+    assert d[:, :12].max() > 0.1 and d[:, 136:766].max() > 0.1 and d[:, 12:124].max() == 0 and d[:, 766:].max() == 0
 
 
 def test_env_reset_vs_reference_golden(genv):

@@ -108,7 +108,9 @@ def test_scene_assembly_and_action_bounds():
     assert np.array_equal(off[5], [4.0, 4.0, 0.0])
     sh = scene.env_offsets_square(8, 2.0, env_id_base=8, total_envs=16)
     assert np.array_equal(sh, off[8:16])
-    cfg = default_config(); cfg["env"]["global_obs"] = True
+    cfg = default_config(); cfg["env"]["global_obs"] = True   # built since round 3 (k_env_post<..., GLOBALOBS>)
+    assert scene.build_scene(cfg, 4, verbose=False).cfg.global_obs == 1
+    cfg = default_config(); cfg["env"]["global_root_height_obs"] = True   # one more observation in front: still rejected
     with pytest.raises(ValueError):
         scene.build_scene(cfg, 4, verbose=False)
     cfg = default_config(); del cfg["env"]["pose_w"]
@@ -312,4 +314,4 @@ def test_dynamics_kernel_of_the_built_library_uses_no_scratch(tmp_path):
     assert wave[0]["private_segment_fixed_size"] == 0, wave[0]
     assert wave[0]["vgpr_count"] > 256, wave[0]        # VGPRs + AGPRs of the one resident wave per SIMD
     post = [v for k, v in kern.items() if "k_env_post" in k]
-    assert len(post) == 6 and all(p["vgpr_count"] <= 102 for p in post), post   # (STEP, OBS) x MIRROR + the two track_root=false STEP instantiations; 5 waves per SIMD need <= 102 registers
+    assert len(post) == 9 and all(p["vgpr_count"] <= 102 for p in post), post   # (STEP, OBS) x MIRROR, the two track_root=false STEP instantiations, three with global_obs; 5 waves per SIMD need <= 102 registers

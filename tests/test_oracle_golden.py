@@ -321,3 +321,29 @@ def test_env_step_without_root_tracking_vs_reference_golden(oracle, orc_char):
     assert np.abs(out[True][0][16:40] - out[False][0][16:40]).max() > 0.05
     assert (out[True][1] != 0).sum() > (out[False][1] != 0).sum()
 
+
+def test_env_step_with_global_observations_vs_reference_golden(oracle, orc_char):
+    """`global_obs: True` (off the default config): compute_char_obs (ig_char_env.py:586-589, :603) and compute_tar_obs
+    (mgdm_dm_util.py:417) leave root rotation, root velocities, root / key offsets in the global frame, and the targets' key offsets are not
+    shifted by the root offset.  env_step_global_obs.npz is the reference's own `_post_physics_step` with that switch."""
+    from helpers import build_oracle_scene, default_cfg, load_state_into
+    g = golden("env_step_global_obs")
+    g0 = golden("env_step")
+    sc = build_oracle_scene(oracle, orc_char, g0)
+    n = g0["env_offsets"].shape[0]
+    st = sc["state"]
+    obs = {}
+    for gl in (True, False):
+        cfg = default_cfg(oracle, n, g0["ray_points"], g0["env_offsets"], g0["motion_offsets"], global_obs=gl)
+        load_state_into(st, g, "in_")
+        oracle.env_post_physics_step(orc_char, sc["lib"], sc["terrain"], cfg, st)
+        oracle.env_update_curriculum(sc["lib"], cfg, st)
+        obs[gl] = st["obs"].copy()
+        if gl:
+            np.testing.assert_allclose(st["obs"], g["out_obs"], atol=1e-5)
+            np.testing.assert_allclose(st["reward"], g["out_reward"], atol=1e-5)
+            assert np.array_equal(st["done"], g["out_done"])
+    d = np.abs(obs[True] - obs[False])
+    assert d[:, :12].max() > 0.1 and d[:, 136:766].max() > 0.1      # the switch changes the root / target blocks ...
+    assert d[:, 12:124].max() == 0 and d[:, 766:].max() == 0         # ... and nothing else: joint rotations, dof velocities, contacts, rays
+
