@@ -152,6 +152,18 @@ def shard_sizes(envs, world, scaling):
     return envs, envs * world
 
 
+def _cpu_model():
+    """Model name of the host CPU (core count and CPU model are stated with the CPU baseline)."""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.lower().startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(env, seconds, dynamics_on, actions):
     """Time the CPU oracle (oracle/parc_oracle.c [+ the host build of the dynamics core]) on the same scene/state,
     all host cores, bounded sample."""
@@ -211,7 +223,7 @@ def cpu_baseline(env, seconds, dynamics_on, actions):
         st["timestep_buf"][:] = steps % 8  # stay inside the clips
         run_step(); steps += 1
     dt = time.time() - t0
-    out = {"value": n * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+    out = {"value": n * steps / dt, "unit": "env-steps/s", "cores": cores, "cpu_model": _cpu_model(), "kind": "port",
            "sample": f"{steps} {'full (dynamics + obs/reward/done)' if dynamics_on else 'kinematic'} steps x {n} envs, C/C++ oracle "
                      "(scalar, -O2, one thread per core), same scene and state"}
     try:
