@@ -297,6 +297,17 @@ def test_env_reset_vs_reference_golden(genv):
 @pytest.mark.parametrize("n", [1, 13, 100, 1023, 4096, 16384])
 def test_env_step_vs_oracle_large(tmp_path, oracle, orc_char, n, mirror):
     """Same seeded state through the HIP step and the CPU oracle at cfg-2/cfg-3 env counts (from-FK bodies)."""
+    _step_vs_oracle(tmp_path, oracle, orc_char, n, mirror, {})
+
+
+# the config branches off the default path (their own k_env_post instantiations), at a ragged env count: the 64-env golden fixtures pin
+# their arithmetic to the reference, this pins the lane layout (short last workgroup, reward owner fall-back) against the oracle
+@pytest.mark.parametrize("variant", [{"track_root": False}, {"global_obs": True}, {"track_root": False, "global_obs": True}])
+def test_config_variants_vs_oracle(tmp_path, oracle, orc_char, variant):
+    _step_vs_oracle(tmp_path, oracle, orc_char, 1023, False, variant)
+
+
+def _step_vs_oracle(tmp_path, oracle, orc_char, n, mirror, variant):
     import torch
     from gpu_helpers import default_config, write_motion_yaml, to_np
     from helpers import CLIPS4, load_clips, make_orc_mlib, default_cfg
@@ -304,15 +315,17 @@ def test_env_step_vs_oracle_large(tmp_path, oracle, orc_char, n, mirror):
     cfg = default_config()
     w = [1.0, 1.5, 2.0, 2.5]
     cfg["env"]["dm"]["motion_file"] = write_motion_yaml(tmp_path, CLIPS4, w)
+    cfg["env"].update(variant)
     env = HipParkourEnv(cfg, n, "cuda:0", False, seed=7, mirror_ref_state=mirror)
-    assert env._lib.parc_env_post_kernel(env._handle).decode() == ("k_env_post<MODE,true>" if mirror else "k_env_post<MODE,false>")
+    general = mirror or variant.get("global_obs", False)
+    assert env._lib.parc_env_post_kernel(env._handle).decode() == ("k_env_post<MODE,true>" if general else "k_env_post<MODE,false>")
     env.reset()
     rng = np.random.default_rng(0)
     steps = 3
     sc = env._scene
     clips = load_clips(CLIPS4)
     lib = make_orc_mlib(oracle, orc_char, clips, w)
-    ocfg = default_cfg(oracle, n, sc.ray_points, sc.env_offsets, sc.grid.motion_offsets)
+    ocfg = default_cfg(oracle, n, sc.ray_points, sc.env_offsets, sc.grid.motion_offsets, **variant)
     ter = oracle.make_terrain(sc.grid.terrain.hf, sc.grid.terrain.min_point, sc.grid.terrain.dxdy)
     st = oracle.make_state(n, M=4, tracking_error=False)
     for s in range(steps):
