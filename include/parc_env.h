@@ -136,6 +136,9 @@ typedef struct {
     /* `global_obs` (ig_parkour_env.py:83; false by default): compute_char_obs (ig_char_env.py:586-589, :603) and compute_tar_obs
      * (mgdm_dm_util.py:417) leave root rotation, root velocities, root / key offsets in the global frame. */
     int32_t global_obs;
+    /* `global_root_height_obs` (ig_parkour_env.py:84, passed on as compute_char_obs's root_height_obs, :904; false by default): the root
+     * height is one more observation in FRONT of the character block (ig_char_env.py:620-622): every later offset moves by one. */
+    int32_t global_root_height_obs;
 } ParcEnvConfig;
 
 /* Motion clips as MotionLib._load_motion_file receives them (motion_lib.py:255-401); the library

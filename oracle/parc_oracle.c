@@ -612,18 +612,22 @@ void orc_env_refresh_rays(const OrcTerrain *t, const OrcEnvCfg *cfg, OrcEnvState
 /* ig_parkour_env.py:842-965 — obs row = [char 136 | tar S*105 | tar_contacts S*B | char_contacts B | hf R] */
 static void compute_obs1(const OrcChar *c, const OrcMotionLib *lib, const OrcEnvCfg *cfg, OrcEnvState *s, int e) {
     int B = c->num_bodies, J = B - 1, D = c->dof_size, K = cfg->num_key, S = cfg->num_tar_steps, R = cfg->num_rays;
-    int char_w = 6 + 3 + 3 + 6 * J + D + 3 * K;
+    const int rh = cfg->root_height_obs ? 1 : 0;   /* compute_char_obs ig_char_env.py:620-622: [root_h] + obs */
+    int char_w = rh + 6 + 3 + 3 + 6 * J + D + 3 * K;
     int tar_w = 3 + 6 + 6 * J + 3 * K;
     int obs_w = char_w + S * tar_w + S * B + B + R;
     float *obs = s->obs + (size_t)e * obs_w;
+    float *const row = obs;
+    obs += rh;                                      /* the character block as laid out without the root height */
     const float *root_pos = s->char_root_pos + 3 * e, *root_rot = s->char_root_rot + 4 * e;
 
     float jr[ORC_MAX_BODIES * 4], body_pos[ORC_MAX_BODIES * 3];
     dof_to_rot1(c, s->char_dof_pos + (size_t)D * e, jr);           /* :865 */
     fk1(c, root_pos, root_rot, jr, body_pos, NULL);                 /* :868 */
 
-    /* compute_char_obs ig_char_env.py:582-627 (root_height_obs False); global_obs: the raw root rotation / velocities / key offsets */
+    /* compute_char_obs ig_char_env.py:582-627; global_obs: the raw root rotation / velocities / key offsets */
     const int gl = cfg->global_obs;
+    if (rh) row[0] = root_pos[2];
     float hinv[4], lr[4];
     calc_heading_quat_inv(root_rot, hinv);
     if (gl) {
@@ -648,7 +652,7 @@ static void compute_obs1(const OrcChar *c, const OrcMotionLib *lib, const OrcEnv
 
     /* DeepMimicEnv.compute_tar_obs dm_env.py:594-626 + fetch_tar_obs_data mgdm_dm_util.py:221 + compute_tar_obs :405 */
     float mt = s->time_buf[e] + s->time_offsets[e]; /* _get_motion_times:547 */
-    float *tar = obs + char_w;
+    float *tar = row + char_w;
     float *tarc = tar + S * tar_w;
     for (int si = 0; si < S; ++si) {
         float tstep = (float)cfg->timestep_d * (float)cfg->tar_obs_steps[si]; /* timestep * tar_obs_steps (f32 tensor) */

@@ -74,6 +74,7 @@ struct MotionMeta { // 32 B
 struct StepParams {
     int N, B, J, D, K, S, R, M, T;
     int lds_wave_floats; // dynamic LDS per wave of k_env_post
+    int global_obs, off_char; // read by the OBSVAR instantiations of k_env_post only
     int obs_dim, off_dofvel, off_key, off_tar, tar_w, off_tarc, off_cc, off_hf;
     float dt_f, episode_length, min_obs_h, max_obs_h;
     float pose_w, vel_w, root_pos_w, root_vel_w, key_pos_w;
@@ -253,9 +254,11 @@ __device__ __forceinline__ float lane_value(float v, int l) { return __int_as_fl
 // scalar spilled to a VGPR lane comes back as a VALU instruction).
 // LOCALROOT = the config's `track_root: false`: the reward compares root rotation, root velocities and key positions in each character's
 // own heading frame (convert_to_local, mgdm_dm_util.py:247-267).  An instantiation of its own so that the default one carries none of it.
-// GLOBALOBS = the config's `global_obs: true`: the character and target observations stay in the global frame (no heading rotation; the
-// targets' key offsets are not shifted by the root offset).  Instantiated with MIRROR = true only (off the default path).
-template <int MODE, bool MIRROR, bool LOCALROOT = false, bool GLOBALOBS = false>
+// OBSVAR = a non-default observation layout, decided at run time inside these instantiations only: `global_obs: true` (P.global_obs: the
+// character and target observations stay in the global frame -- no heading rotation, the targets' key offsets are not shifted by the root
+// offset) and / or `global_root_height_obs: true` (P.off_char = 1: the root height in front of the character block).  Instantiated with
+// MIRROR = true only (off the default path).
+template <int MODE, bool MIRROR, bool LOCALROOT = false, bool OBSVAR = false>
 __global__ __launch_bounds__(256, 5) void k_env_post(const StepParams P, const int64_t *__restrict__ env_ids,
                                                  const int *__restrict__ env_ids32, const int *__restrict__ count_dev, int count,
                                                  unsigned long long *bump_calls) {
@@ -282,6 +285,8 @@ __global__ __launch_bounds__(256, 5) void k_env_post(const StepParams P, const i
 #endif
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
+    const bool GLOBALOBS = OBSVAR && P.global_obs != 0; // a compile-time false in the default instantiations
+    const int oc = OBSVAR ? P.off_char : 0;              // offset of the character block (1 when the root height leads the row)
     float *s_obs = s_obs_all + (size_t)wv * P.lds_wave_floats;
     float4 (*s_q)[16] = s_q_all[wv];
     float4 (*s_lq)[16] = s_lq_all[wv];
@@ -425,9 +430,10 @@ __global__ __launch_bounds__(256, 5) void k_env_post(const StepParams P, const i
         s_cdofv[lane] = dofv;
         s_obs[P.off_dofvel + lane] = dofv;
     }
+    if (OBSVAR && oc && lane == 29) s_obs[0] = root_pos.z; // root_height_obs (ig_char_env.py:620-622)
     if (lane == 30 || lane == 31) { // root velocities in the heading frame (ig_char_env.py:593-597)
         const V3 r = GLOBALOBS ? mk3(aux0, aux1, aux2) : quat_rotate(hinv, mk3(aux0, aux1, aux2));
-        const int o = lane == 30 ? 6 : 9;
+        const int o = oc + (lane == 30 ? 6 : 9);
         s_obs[o + 0] = r.x; s_obs[o + 1] = r.y; s_obs[o + 2] = r.z;
     }
     if (lane >= 32 && lane < 32 + B) { // contact flags + clamped force norms (ig_parkour_env.py:655-662, mgdm_dm_util.py:505-508)
@@ -557,7 +563,7 @@ __global__ __launch_bounds__(256, 5) void k_env_post(const StepParams P, const i
                     const Q4 qq = (i == 0 && !GLOBALOBS) ? quat_mul(hinv, res) : res;
                     float tn[6];
                     quat_to_tan_norm(qq, tn);
-                    const int o = r == 0 ? (i == 0 ? 0 : 12 + 6 * (i - 1)) : base + 3 + 6 * i;
+                    const int o = r == 0 ? oc + (i == 0 ? 0 : 12 + 6 * (i - 1)) : base + 3 + 6 * i;
 #pragma unroll
                     for (int c = 0; c < 6; ++c) s_obs[o + c] = tn[c];
                 } else if (i == 15 && r >= 2) {
@@ -1698,7 +1704,8 @@ extern "C" int parc_env_create(const ParcEnvConfig *cfg, ParcEnv **out) {
     memset(&sp, 0, sizeof(sp));
     sp.N = e->N; sp.B = B; sp.J = J; sp.D = D; sp.K = K; sp.S = S; sp.R = R;
     // observation layout (ig_parkour_env.py:842-965)
-    sp.off_dofvel = 12 + 6 * J;
+    sp.global_obs = cfg->global_obs; sp.off_char = cfg->global_root_height_obs ? 1 : 0;
+    sp.off_dofvel = sp.off_char + 12 + 6 * J;
     sp.off_key = sp.off_dofvel + D;
     sp.off_tar = sp.off_key + 3 * K;
     sp.tar_w = 3 + 6 + 6 * J + 3 * K;
@@ -2001,7 +2008,7 @@ static int launch_post(ParcEnv *e, int mode, const int64_t *ids, int count, hipS
     if (mode == MODE_STEP && e->cfg.enable_dynamics && e->use_wave) prep_done = true; // k_dynamics_wave wrote the prep records with the state
     if (!prep_done) hipLaunchKernelGGL(k_env_prep, dim3((count + 3) / 4), dim3(64), 0, st, e->sp, ids, ids32, count_dev, count);
     const bool mirror = wants_mirror(e->sp.buf);
-    if (e->cfg.global_obs) { // global_obs: true -- instantiated for the general (MIRROR) form only
+    if (e->cfg.global_obs || e->cfg.global_root_height_obs) { // a non-default observation layout -- instantiated for the general (MIRROR) form only
         if (mode == MODE_STEP && !e->sp.track_root) hipLaunchKernelGGL((k_env_post<MODE_STEP, true, true, true>), dim3(grid), dim3(64 * ENVS_PER_BLOCK), lds, st, e->sp, ids, ids32, count_dev, count, bump);
         else if (mode == MODE_STEP) hipLaunchKernelGGL((k_env_post<MODE_STEP, true, false, true>), dim3(grid), dim3(64 * ENVS_PER_BLOCK), lds, st, e->sp, ids, ids32, count_dev, count, bump);
         else hipLaunchKernelGGL((k_env_post<MODE_OBS, true, false, true>), dim3(grid), dim3(64 * ENVS_PER_BLOCK), lds, st, e->sp, ids, ids32, count_dev, count, bump);
@@ -2487,7 +2494,7 @@ extern "C" const char *parc_env_dynamics_kernel(ParcEnv *e) {
 
 extern "C" const char *parc_env_post_kernel(ParcEnv *e) {
     if (!e || !e->bound) return "";
-    return (wants_mirror(e->sp.buf) || e->cfg.global_obs) ? "k_env_post<MODE,true>" : "k_env_post<MODE,false>";
+    return (wants_mirror(e->sp.buf) || e->cfg.global_obs || e->cfg.global_root_height_obs) ? "k_env_post<MODE,true>" : "k_env_post<MODE,false>";
 }
 
 #ifdef PARC_STAMPS

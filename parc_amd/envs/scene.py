@@ -131,9 +131,6 @@ def build_scene(config: dict, num_envs: int, device_index: int = 0, env_id_base:
     _ = env_config["contact_detection_eps"]  # read but unused by the reference too (ig_parkour_env.py:55,655)
     if not env_config["use_contact_info"]:
         raise ValueError("use_contact_info: false is not supported")
-    if env_config["global_root_height_obs"]:
-        # _compute_obs passes root_height_obs=self._global_root_height_obs (ig_parkour_env.py:900): one more observation in front
-        raise ValueError("global_root_height_obs: true is not supported")
     if not env_config.get("enable_tar_obs", True):
         raise ValueError("enable_tar_obs: false is not supported")
     if env_config.get("control_mode", "pd") != "pd":
@@ -251,11 +248,13 @@ def build_scene(config: dict, num_envs: int, device_index: int = 0, env_id_base:
     cfg.contact_body_mask = mask
     cfg.termination_height = float(env_config["termination_height"])
     cfg.global_obs = int(bool(env_config["global_obs"]))   # ig_parkour_env.py:83
+    # _compute_obs passes root_height_obs=self._global_root_height_obs (ig_parkour_env.py:904): one more observation in front
+    cfg.global_root_height_obs = int(bool(env_config["global_root_height_obs"]))
 
     from collections import OrderedDict
     J, K, S, R = B - 1, len(key_body_ids), len(tar_obs_steps), ray.shape[0]
     obs_shapes = OrderedDict()  # ig_parkour_env.py:911-958
-    obs_shapes["char_obs"] = {"use_normalizer": True, "shape": (6 + 3 + 3 + 6 * J + D + 3 * K,)}
+    obs_shapes["char_obs"] = {"use_normalizer": True, "shape": (int(bool(env_config["global_root_height_obs"])) + 6 + 3 + 3 + 6 * J + D + 3 * K,)}
     obs_shapes["tar_obs"] = {"use_normalizer": True, "shape": (S, 3 + 6 + 6 * J + 3 * K)}
     obs_shapes["tar_contacts"] = {"use_normalizer": False, "shape": (S, B)}
     obs_shapes["char_contacts"] = {"use_normalizer": False, "shape": (B,)}

@@ -59,7 +59,7 @@ class ParcEnvConfig(C.Structure):
                 ("env_offsets_host", f32p), ("action_low", C.c_float * MAX_DOFS), ("action_high", C.c_float * MAX_DOFS),
                 ("body_pos_from_fk", C.c_int32), ("enable_dynamics", C.c_int32), ("dynamics", ParcDynamicsParams),
                 ("seed", C.c_uint64), ("contact_body_mask", C.c_uint32), ("termination_height", C.c_float),
-                ("global_obs", C.c_int32)]
+                ("global_obs", C.c_int32), ("global_root_height_obs", C.c_int32)]
 
 
 class ParcMotionClips(C.Structure):

@@ -427,7 +427,7 @@ def build_harness(m, clips, num_envs, cfg):
     env._actors_need_reset = torch.zeros(num_envs, 1, dtype=torch.bool)
     env._info = dict()
     env._give_data_buffer_views()
-    env._obs_buf = z(num_envs, 1312)
+    env._obs_buf = z(num_envs, 1312 + int(bool(env_config_["global_root_height_obs"])))  # root_height_obs leads the row (ig_char_env.py:620)
     # Isaac Gym refresh calls are no-ops here: the caller injects the sim tensors
     env._refresh_sim_tensors = lambda: ipe.IGParkourEnv._refresh_obs_hfs(env)
     env.write_agent_states = lambda: None
@@ -614,6 +614,31 @@ def gen_env_step_local_root(m):
     print("local-root fixture: done histogram", np.bincount(npy(env._done_buf), minlength=4), "reward range", float(env._reward_buf.min()), float(env._reward_buf.max()))
 
 
+def gen_env_step_root_height_obs(m):
+    """`global_root_height_obs: True` (ig_parkour_env.py:84, passed to compute_char_obs as root_height_obs, :904): the root height is one
+    more observation in front of the character block (ig_char_env.py:620-622) -- 1 313 columns.  With and without `global_obs`."""
+    for gl in (False, True):
+        cfg = env_config()
+        cfg["env"]["global_root_height_obs"] = True
+        cfg["env"]["global_obs"] = gl
+        n = 64
+        env, dm = build_harness(m, CLIPS, n, cfg)
+        g = torch.Generator().manual_seed(41)
+        torch.manual_seed(55)
+        dm.reset(torch.arange(n))
+        env._refresh_sim_tensors()
+        env._update_observations(torch.arange(n))
+        assert env._obs_buf.shape[1] == 1313
+        arrs = {"global_obs": np.int32(gl), "global_root_height_obs": np.int32(1), "reset_obs": npy(env._obs_buf)}
+        arrs.update(state_dict(env, dm, "reset_"))
+        env._timestep_buf[:] = torch.randint(1, 40, (n,), generator=g, dtype=torch.int32)
+        inject_state(env, dm, m, g, noise=0.02, big_noise_rows=(6, 7, 8, 9))
+        arrs.update(state_dict(env, dm, "in_"))
+        ig_env.IGEnv._post_physics_step(env)
+        arrs.update(out_dict(env, dm, "out_"))
+        save("env_step_root_height_obs" + ("_global" if gl else ""), **arrs)
+
+
 def gen_env_step_global_obs(m):
     """`global_obs: True` (ig_parkour_env.py:83): compute_char_obs (ig_char_env.py:586-589, :603) keeps the root rotation, the root
     velocities and the key-body offsets in the global frame; compute_tar_obs (mgdm_dm_util.py:417) keeps the targets' root offset, root
@@ -678,3 +703,4 @@ if __name__ == "__main__":
     gen_env_step_fall(model)
     gen_env_step_local_root(model)
     gen_env_step_global_obs(model)
+    gen_env_step_root_height_obs(model)

@@ -110,7 +110,10 @@ def test_scene_assembly_and_action_bounds():
     assert np.array_equal(sh, off[8:16])
     cfg = default_config(); cfg["env"]["global_obs"] = True   # built since round 3 (k_env_post<..., GLOBALOBS>)
     assert scene.build_scene(cfg, 4, verbose=False).cfg.global_obs == 1
-    cfg = default_config(); cfg["env"]["global_root_height_obs"] = True   # one more observation in front: still rejected
+    cfg = default_config(); cfg["env"]["global_root_height_obs"] = True   # one more observation in front (built since round 3)
+    sc1 = scene.build_scene(cfg, 4, verbose=False)
+    assert sc1.cfg.global_root_height_obs == 1 and sc1.obs_shapes["char_obs"]["shape"] == (137,)
+    cfg = default_config(); cfg["env"]["use_contact_info"] = False          # still rejected
     with pytest.raises(ValueError):
         scene.build_scene(cfg, 4, verbose=False)
     cfg = default_config(); del cfg["env"]["pose_w"]

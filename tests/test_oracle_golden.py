@@ -347,3 +347,26 @@ def test_env_step_with_global_observations_vs_reference_golden(oracle, orc_char)
     assert d[:, :12].max() > 0.1 and d[:, 136:766].max() > 0.1      # the switch changes the root / target blocks ...
     assert d[:, 12:124].max() == 0 and d[:, 766:].max() == 0         # ... and nothing else: joint rotations, dof velocities, contacts, rays
 
+
+@pytest.mark.parametrize("gl", [False, True])
+def test_env_step_with_root_height_observation_vs_reference_golden(oracle, orc_char, gl):
+    """`global_root_height_obs: True` (off the default config): the root height leads the character block (compute_char_obs
+    ig_char_env.py:620-622), 1 313 columns -- alone and together with `global_obs`.  Fixtures: the reference's own `_post_physics_step`."""
+    from helpers import default_cfg, load_clips, load_state_into, make_orc_mlib
+    g = golden("env_step_root_height_obs" + ("_global" if gl else ""))
+    g0 = golden("env_step")
+    assert int(g["global_obs"]) == int(gl) and g["out_obs"].shape[1] == 1313
+    n = g0["env_offsets"].shape[0]
+    clips = load_clips([str(c) for c in g0["clips"]])
+    lib = make_orc_mlib(oracle, orc_char, clips, [1.0, 1.5, 2.0, 2.5])
+    ter = oracle.make_terrain(g0["hf"], g0["hf_min_point"], g0["hf_dxdy"])
+    st = oracle.make_state(n, M=len(clips), obs_w=1313)
+    cfg = default_cfg(oracle, n, g0["ray_points"], g0["env_offsets"], g0["motion_offsets"], global_obs=gl, global_root_height_obs=True)
+    load_state_into(st, g, "in_")
+    oracle.env_post_physics_step(orc_char, lib, ter, cfg, st)
+    oracle.env_update_curriculum(lib, cfg, st)
+    np.testing.assert_allclose(st["obs"], g["out_obs"], atol=1e-5)
+    np.testing.assert_allclose(st["reward"], g["out_reward"], atol=1e-5)
+    assert np.array_equal(st["done"], g["out_done"])
+    np.testing.assert_array_equal(st["obs"][:, 0], st["char_root_pos"][:, 2])      # the leading column IS the root height
+
