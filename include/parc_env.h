@@ -264,6 +264,9 @@ int parc_env_profile_step(ParcEnv *env, const float *action_dev, void *stream, i
 /* The waves of a k_dynamics_wave block hand records to each other through LDS flags; a wait is bounded so that a protocol
  * error cannot hang the GPU.  Number of waits that ever hit the bound on this device (synchronises; must be 0; < 0 = error). */
 int parc_env_dynamics_timeouts(ParcEnv *env);
+/* Contact planes the dynamics kernel had no room for since the library was loaded (its per-lane plane list and overflow area were full):
+ * must stay 0.  Synchronises the device. */
+int parc_env_dynamics_manifold_drops(ParcEnv *env);
 
 /* average duration of k_dynamics in the last parc_env_profile_step call (0 when dynamics is off) */
 float parc_env_last_dynamics_ms(ParcEnv *env);

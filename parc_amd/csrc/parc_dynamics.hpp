@@ -92,6 +92,16 @@ struct DynModel {
     int nsub;                    // substeps per control step (sim_steps * substeps)
     float kn, dn, dtang, mu;     // contact stiffness / normal damping / tangential damping / friction
     float pen_cap;               // penetration beyond which the contact spring saturates (PhysX max_depenetration_velocity, see fill_dyn_model)
+    // CONTACT MANIFOLD (round 4).  Contacts are DISCOVERED (candidate spheres against the cell columns: the expensive, divergent part)
+    // in substeps 0, man_period, 2 man_period, ... of a control step and kept as PLANES (body-frame point, world normal, offset, weight);
+    // every substep re-evaluates penetration and velocity along the cached planes (contact_apply on pen > 0).  Discovery also keeps
+    // SPECULATIVE planes: candidates that are not touching yet but could within the substeps that follow (pen > -margin, margin =
+    // min(spec_m0 + spec_tv * approach speed along the normal, spec_max)), so a foot coming down is caught by the plane it is about to hit.
+    // PhysX does the same in spirit: shapes closer than contact_offset (0.02 m, dm_env_default.yaml sim.physx) generate contacts before
+    // they touch, and its persistent contact manifold is re-used while the relative pose has moved little.  man_period = 1 is the
+    // round-3 behaviour (discovery in every substep; the speculative planes then never carry a force).
+    int man_period;
+    float spec_m0, spec_tv, spec_max;
     float lim_k, lim_d;          // joint-limit penalty
     float max_ang_vel, ang_damping;
     float total_mass;
@@ -355,6 +365,41 @@ PARC_HD float segment_edge_point(const DynTerrain &T, v3 A, v3 Bv, TopAt top_at,
     return (ok_[0] || ok_[1]) ? w : 0.f;
 }
 
+// ---------------------------------------------------------------- contact manifold
+#define DYN_MAXM 128  // planes of one env (reference statement; the wave kernel keeps per-wave lists in LDS with an overflow area, see there)
+struct ContactPlane {
+    int body;
+    v3 p;      // the contact point of the candidate sphere's centre, BODY frame
+    v3 n;      // unit normal, world axes (the terrain does not move)
+    float off; // pen(g) = off - n . g for the sphere centre at g (local frame of the build: see dyn_control_step)
+    float w;   // stiffness / damping weight (1 for a collision point; the position weight of a segment's edge candidate)
+};
+struct Manifold { int n; ContactPlane e[DYN_MAXM]; };
+PARC_HD float spec_margin(const DynModel &M, float vn) {
+    const float m = M.spec_m0 + M.spec_tv * (vn < 0.f ? -vn : 0.f);
+    return m < M.spec_max ? m : M.spec_max;
+}
+// Discovery for one candidate sphere (centre g in the frame of T, radius rad, velocity vpt): the column of its own cell and the higher
+// neighbours (walls / step edges); emit(pen, n) for every contact within the speculative margin.  `top_at(ix, iy)` returns a column top.
+template <class TopAt, class Emit>
+PARC_HD void sphere_discover(const DynModel &M, const DynTerrain &T, v3 g, float rad, v3 vpt, TopAt top_at, Emit emit) {
+    const int ix = cell_of(g.x, T.min_x, T.dx), iy = cell_of(g.y, T.min_y, T.dy);
+    const float top0 = top_at(ix, iy);
+    const float zlo = g.z - rad - spec_margin(M, vpt.z);
+    for (int nb = 0; nb < 9; ++nb) {
+        const int jx = ix + (nb % 3) - 1, jy = iy + (nb / 3) - 1;
+        const bool own = nb == 4;
+        const float top = own ? top0 : top_at(jx, jy);
+        if (!own && !(top > top0 + 1e-3f)) continue; // only higher neighbours act as walls / step edges
+        if (zlo > top) continue;
+        v3 n;
+        const float pen = own ? own_column_contact(T, g, rad, ix, iy, top0, [&](int ox, int oy) { return top_at(ix + ox, iy + oy); }, n)
+                              : sphere_vs_column(T, g, rad, jx, jy, top, n);
+        if (!(pen > -spec_margin(M, dot(vpt, n)))) continue;
+        emit(pen, n);
+    }
+}
+
 // One contact (point at x relative to O with velocity vpt, penetration pen along the unit normal n): explicit force into
 // pA and the force report, implicit term dt X^T (beta 1 + (bn - beta) n n^T) X into IA.
 // `w` scales the contact's stiffness and damping (1 for a collision point; the position weight of a segment's edge candidate).
@@ -418,6 +463,8 @@ PARC_HD void dyn_control_step(const DynModel &M, const DynTerrain &T, const DynS
     Patch patch;
     load_patch(T, rp.x + env_off[0], rp.y + env_off[1], patch);
     v3 fcon[DYN_MAXB]; // net contact force of the last substep
+    Manifold man; man.n = 0;
+    v3 rp_d = rp;      // root position at the last discovery
 
     for (int sub = 0; sub < M.nsub; ++sub) {
         // ---- kinematics relative to O = root origin --------------------------------------------------------
@@ -462,41 +509,47 @@ PARC_HD void dyn_control_step(const DynModel &M, const DynTerrain &T, const DynS
             fcon[i] = mk(0.f, 0.f, 0.f);
         }
         // ---- contacts: explicit force + implicit (dt*B) inertia term ----------------------------------------
-        // remembered per active contact for the force report: body, arm x, B-matrix pieces
-        // one collision sphere (centre x relative to O = g in global coordinates, radius rad) of body i against the column of its own
-        // cell and the higher neighbours
-        auto sphere_contacts = [&](int i, v3 x, v3 g, float rad, float w) {
-            const int ix = cell_of(g.x, T.min_x, T.dx), iy = cell_of(g.y, T.min_y, T.dy);
-            const float top0 = patch_h(T, patch, ix, iy);
-            v3 vpt = s6lin(vel[i]) + cross(s6ang(vel[i]), x);
-            for (int nb = 0; nb < 9; ++nb) {
-                const int jx = ix + (nb % 3) - 1, jy = iy + (nb / 3) - 1;
-                const bool own = (jx == ix && jy == iy);
-                const float top = own ? top0 : patch_h(T, patch, jx, jy);
-                if (!own && !(top > top0 + 1e-3f)) continue; // only higher neighbours act as walls / step edges
-                if (g.z - rad > top) continue;
-                v3 n;
-                const float pen = own ? own_column_contact(T, g, rad, ix, iy, top0, [&](int ox, int oy) { return patch_h(T, patch, ix + ox, iy + oy); }, n)
-                                      : sphere_vs_column(T, g, rad, jx, jy, top, n);
-                if (!(pen > 0.f)) continue;
-                // explicit force + implicit part dt * X^T (beta 1 + (bn - beta) n n^T) X, bn = dn + dt*kn (only while pushing)
-                contact_apply(M, dt, x, vpt, pen, n, IA[i], pA[i], fcon[i], w);
+        // Discovery (substeps 0, man_period, ...): every collision point and every segment's edge candidate against the columns it can
+        // reach within the speculative margin -> planes.  The planes live in the ROOT-AT-DISCOVERY frame (world axes, origin = the root
+        // position rp_d of that substep): the coordinates n . g stay small (the env-local frame reaches ~1 km at 65 536 envs).
+        if (sub % M.man_period == 0) {
+            man.n = 0; rp_d = rp;
+            const v3 goff = mk(rp.x + env_off[0], rp.y + env_off[1], rp.z + env_off[2]);
+            auto top_at = [&](int ix, int iy) { return patch_h(T, patch, ix, iy); };
+            auto candidate = [&](int i, v3 x, float rad, float w) {
+                const v3 vpt = s6lin(vel[i]) + cross(s6ang(vel[i]), x);
+                sphere_discover(M, T, x + goff, rad, vpt, top_at, [&](float pen, v3 n) {
+                    if (man.n >= DYN_MAXM) return;
+                    ContactPlane &P = man.e[man.n++];
+                    P.body = i; P.p = mulTv(R[i], x - r[i]); P.n = n; P.off = pen + dot(n, x); P.w = w;
+                });
+            };
+            for (int k = 0; k < M.ncol; ++k) {
+                const int i = M.col_body[k];
+                candidate(i, r[i] + mulv(R[i], mk(M.col_pos[k][0], M.col_pos[k][1], M.col_pos[k][2])), M.col_r[k], 1.f);
             }
-        };
-        const v3 goff = mk(rp.x + env_off[0], rp.y + env_off[1], rp.z + env_off[2]);
-        for (int k = 0; k < M.ncol; ++k) {
-            const int i = M.col_body[k];
-            const v3 x = r[i] + mulv(R[i], mk(M.col_pos[k][0], M.col_pos[k][1], M.col_pos[k][2])); // relative to O
-            sphere_contacts(i, x, x + goff, M.col_r[k], 1.f);
+            // shafts of capsules / sole edges of boxes against the top edges of the columns (segment_edge_point)
+            for (int k = 0; k < M.nseg; ++k) {
+                const int i = M.seg_body[k];
+                const v3 xa = r[i] + mulv(R[i], mk(M.seg_a[k][0], M.seg_a[k][1], M.seg_a[k][2]));
+                const v3 xb = r[i] + mulv(R[i], mk(M.seg_b[k][0], M.seg_b[k][1], M.seg_b[k][2]));
+                v3 Q;
+                const float w = segment_edge_point(T, xa + goff, xb + goff, top_at, Q);
+                if (w > 0.f) candidate(i, Q - goff, M.seg_r[k], w);
+            }
         }
-        // shafts of capsules / sole edges of boxes against the top edges of the columns (segment_edge_point)
-        for (int k = 0; k < M.nseg; ++k) {
-            const int i = M.seg_body[k];
-            const v3 xa = r[i] + mulv(R[i], mk(M.seg_a[k][0], M.seg_a[k][1], M.seg_a[k][2]));
-            const v3 xb = r[i] + mulv(R[i], mk(M.seg_b[k][0], M.seg_b[k][1], M.seg_b[k][2]));
-            v3 Q;
-            const float w = segment_edge_point(T, xa + goff, xb + goff, [&](int ix, int iy) { return patch_h(T, patch, ix, iy); }, Q);
-            if (w > 0.f) sphere_contacts(i, Q - goff, Q, M.seg_r[k], w);
+        // Evaluation (every substep): penetration and velocity along the cached planes
+        {
+            const v3 shift = rp - rp_d;
+            for (int c = 0; c < man.n; ++c) {
+                const ContactPlane &P = man.e[c];
+                const int i = P.body;
+                const v3 x = r[i] + mulv(R[i], P.p);
+                const float pen = P.off - dot(P.n, x + shift);
+                if (!(pen > 0.f)) continue;
+                const v3 vpt = s6lin(vel[i]) + cross(s6ang(vel[i]), x);
+                contact_apply(M, dt, x, vpt, pen, P.n, IA[i], pA[i], fcon[i], P.w);
+            }
         }
         // ---- inward pass ------------------------------------------------------------------------------------
         float Dinv[DYN_MAXB][6]; // symmetric 3x3 inverse: xx yy zz xy xz yz (hinge uses [0])
@@ -812,6 +865,12 @@ inline void fill_dyn_model(DynModel &M, const ParcCharModel &cm, const ParcDynam
     // dm_env_default.yaml sim.physx).  A spring-damper contact pushes out at v = kn pen / dn once spring and damper balance,
     // so the same bound is a cap on the penetration the spring sees: pen_cap = v_max dn / kn (0.1 m for 10 m/s).
     M.pen_cap = (dp.max_depenetration_velocity > 0.f ? dp.max_depenetration_velocity : 10.f) * M.dn / M.kn;
+    // manifold: discovery once per control step; margin = PhysX's contact_offset + 1.5 x what a point covers at its approach speed until the
+    // next discovery, capped so that (largest sphere + margin) stays under half a cell (the near-side-only neighbour logic of the wave kernel)
+    M.man_period = M.nsub;
+    M.spec_m0 = dp.contact_offset > 0.f ? dp.contact_offset : 0.02f;
+    M.spec_tv = 1.5f * (float)(M.man_period - 1) * M.dt;
+    M.spec_max = 0.08f;
     M.lim_k = 1.0e3f; M.lim_d = 5.0e1f;
     M.max_ang_vel = dp.max_angular_velocity > 0.f ? dp.max_angular_velocity : 100.f;
     M.ang_damping = dp.angular_damping;

@@ -118,6 +118,7 @@ inline bool build_coop_tables(const DynModel &M, CoopTables &C) {
 // per-body joint-space factors kept in LDS between the inward and the outward pass:
 // [0,6) cJ  [6,24) U (3 columns)  [24,30) Dinv  [30,33) u
 #define CO_JNT 33
+#define CO_MAXM 48  // contact planes of one chain (4 per candidate at most; the humanoid's legs have 16 candidates)
 
 #ifdef PARC_STAMPS
 __device__ unsigned long long g_dyn_stamps[16];
@@ -199,6 +200,12 @@ __global__ __launch_bounds__(64, 1) void k_dynamics_coop(const DynModel *__restr
     v3 fcon[CO_MAXLEN];
 #pragma unroll
     for (int k = 0; k < CO_MAXLEN; ++k) fcon[k] = mk(0.f, 0.f, 0.f);
+    // contact planes of this lane's chain (parc_dynamics.hpp, contact manifold): private memory -- this kernel is the general fallback and
+    // the cross-check of k_dynamics_wave, not the fast path
+    ContactPlane man[CO_MAXM];
+    int man_n = 0, man_start[CO_MAXLEN], man_end[CO_MAXLEN];
+    for (int k = 0; k < CO_MAXLEN; ++k) { man_start[k] = 0; man_end[k] = 0; }
+    v3 rootp_d = mk(0.f, 0.f, 0.f);
     __syncthreads();
     // a body whose bounding sphere clears every column its collision spheres could touch (own cell +-1 for the sphere
     // centres, +-1 more for the neighbour columns) skips the contact loop; exact, since those contributions are zero
@@ -308,54 +315,57 @@ __global__ __launch_bounds__(64, 1) void k_dynamics_coop(const DynModel *__restr
                             pA.a[3] += pb.a[3] - fg.x; pA.a[4] += pb.a[4] - fg.y; pA.a[5] += pb.a[5] - fg.z;
                         }
                         DSTAMP(3);
-                        // contacts of this body
+                        // contacts of this body: discovery into this lane's planes (substeps 0, man_period, ...; parc_dynamics.hpp, contact
+                        // manifold), then the evaluation of the body's planes
                         v3 fsum = mk(0.f, 0.f, 0.f);
-                        int npt_b = C.npt[b];
-                        {
-                            const int bx = cell_of(r.x + rootp.x + eo0, T.min_x, T.dx) - s_pox[el], by = cell_of(r.y + rootp.y + eo1, T.min_y, T.dy) - s_poy[el];
-                            if (C.brad[b] < cell_min && bx >= 2 && bx < DYN_PATCH - 2 && by >= 2 && by < DYN_PATCH - 2 &&
-                                r.z + rootp.z + eo2 - C.brad[b] > s_pmax[el][(bx - 2) * (DYN_PATCH - 4) + by - 2]) npt_b = 0;
-                        }
-                        // one collision sphere (centre x relative to O, g in global coordinates) against its own column and the higher neighbours
-                        auto sphere_contacts = [&](v3 x, v3 g, float rad, float w) {
-                            const int ix = cell_of(g.x, T.min_x, T.dx), iy = cell_of(g.y, T.min_y, T.dy);
-                            const int pa_ = ix - s_pox[el], pb_ = iy - s_poy[el];
-                            const bool inp = pa_ >= 1 && pa_ < DYN_PATCH - 1 && pb_ >= 1 && pb_ < DYN_PATCH - 1;
-                            const float top0 = inp ? s_patch[el][pa_ * DYN_PATCH + pb_] : hf_at(T, ix, iy);
-                            const v3 vpt = s6lin(velk) + cross(s6ang(velk), x);
-                            PARC_UNROLL
-                            for (int nb = 0; nb < 9; ++nb) {
-                                const int ox_ = (nb % 3) - 1, oy_ = (nb / 3) - 1;
-                                const bool own = nb == 4;
-                                const float top = own ? top0 : (inp ? s_patch[el][(pa_ + ox_) * DYN_PATCH + pb_ + oy_] : hf_at(T, ix + ox_, iy + oy_));
-                                if (!own && !(top > top0 + 1e-3f)) continue;
-                                if (g.z - rad > top) continue;
-                                v3 n;
-                                const float pen = own ? own_column_contact(T, g, rad, ix, iy, top0, [&](int ox, int oy) {
-                                                            return inp ? s_patch[el][(pa_ + ox) * DYN_PATCH + pb_ + oy] : hf_at(T, ix + ox, iy + oy); }, n)
-                                                      : sphere_vs_column(T, g, rad, ix + ox_, iy + oy_, top, n);
-                                if (!(pen > 0.f)) continue;
-                                contact_apply(Mg, dt, x, vpt, pen, n, IA, pA, fsum, w);
+                        if (sub % Mg.man_period == 0) {
+                            if (k == my_len - 1) { man_n = 0; rootp_d = rootp; }
+                            man_start[k] = man_n;
+                            int npt_b = C.npt[b];
+                            {   // exact cull: the body's bounding sphere (+ the largest margin) clears every column its spheres could reach
+                                const int bx = cell_of(r.x + rootp.x + eo0, T.min_x, T.dx) - s_pox[el], by = cell_of(r.y + rootp.y + eo1, T.min_y, T.dy) - s_poy[el];
+                                if (C.brad[b] < cell_min && bx >= 2 && bx < DYN_PATCH - 2 && by >= 2 && by < DYN_PATCH - 2 &&
+                                    r.z + rootp.z + eo2 - C.brad[b] - Mg.spec_max > s_pmax[el][(bx - 2) * (DYN_PATCH - 4) + by - 2]) npt_b = 0;
                             }
-                        };
-                        const v3 goff = mk(rootp.x + eo0, rootp.y + eo1, rootp.z + eo2);
-                        for (int pi = 0; pi < npt_b; ++pi) {
-                            const int kp = C.pt0[b] + pi;
-                            const v3 x = r + mulv(R, mk(M.col_pos[kp][0], M.col_pos[kp][1], M.col_pos[kp][2]));
-                            sphere_contacts(x, x + goff, M.col_r[kp], 1.f);
-                        }
-                        // shafts of capsules / sole edges against the columns' top edges (segment_edge_point); the segments' ends are
-                        // collision points, so the body-level cull above covers them
-                        const int nsg_b = npt_b > 0 ? C.nsg[b] : 0;
-                        for (int si = 0; si < nsg_b; ++si) {
-                            const int ks = C.sg0[b] + si;
-                            const v3 xa = r + mulv(R, mk(M.seg_a[ks][0], M.seg_a[ks][1], M.seg_a[ks][2]));
-                            const v3 xb = r + mulv(R, mk(M.seg_b[ks][0], M.seg_b[ks][1], M.seg_b[ks][2]));
-                            v3 Q;
-                            const float wq = segment_edge_point(T, xa + goff, xb + goff, [&](int ix, int iy) {
+                            auto top_at = [&](int ix, int iy) {
                                 const int a_ = ix - s_pox[el], b_ = iy - s_poy[el];
-                                return (a_ >= 0 && a_ < DYN_PATCH && b_ >= 0 && b_ < DYN_PATCH) ? s_patch[el][a_ * DYN_PATCH + b_] : hf_at(T, ix, iy); }, Q);
-                            if (wq > 0.f) sphere_contacts(Q - goff, Q, M.seg_r[ks], wq);
+                                return (a_ >= 0 && a_ < DYN_PATCH && b_ >= 0 && b_ < DYN_PATCH) ? s_patch[el][a_ * DYN_PATCH + b_] : hf_at(T, ix, iy); };
+                            const v3 goff = mk(rootp.x + eo0, rootp.y + eo1, rootp.z + eo2);
+                            auto candidate = [&](v3 x, float rad, float w) {
+                                const v3 vpt = s6lin(velk) + cross(s6ang(velk), x);
+                                sphere_discover(Mg, T, x + goff, rad, vpt, top_at, [&](float pen, v3 n) {
+                                    if (man_n >= CO_MAXM) return;
+                                    ContactPlane &P = man[man_n++];
+                                    P.body = k; P.p = mulTv(R, x - r); P.n = n; P.off = pen + dot(n, x); P.w = w;
+                                });
+                            };
+                            for (int pi = 0; pi < npt_b; ++pi) {
+                                const int kp = C.pt0[b] + pi;
+                                candidate(r + mulv(R, mk(M.col_pos[kp][0], M.col_pos[kp][1], M.col_pos[kp][2])), M.col_r[kp], 1.f);
+                            }
+                            // shafts of capsules / sole edges against the columns' top edges (segment_edge_point); the segments' ends are
+                            // collision points, so the body-level cull above covers them
+                            const int nsg_b = npt_b > 0 ? C.nsg[b] : 0;
+                            for (int si = 0; si < nsg_b; ++si) {
+                                const int ks = C.sg0[b] + si;
+                                const v3 xa = r + mulv(R, mk(M.seg_a[ks][0], M.seg_a[ks][1], M.seg_a[ks][2]));
+                                const v3 xb = r + mulv(R, mk(M.seg_b[ks][0], M.seg_b[ks][1], M.seg_b[ks][2]));
+                                v3 Q;
+                                const float wq = segment_edge_point(T, xa + goff, xb + goff, top_at, Q);
+                                if (wq > 0.f) candidate(Q - goff, M.seg_r[ks], wq);
+                            }
+                            man_end[k] = man_n;
+                        }
+                        {
+                            const v3 shift = rootp - rootp_d;
+                            for (int ci = man_start[k]; ci < man_end[k]; ++ci) {
+                                const ContactPlane &P = man[ci];
+                                const v3 x = r + mulv(R, P.p);
+                                const float pen = P.off - dot(P.n, x + shift);
+                                if (!(pen > 0.f)) continue;
+                                const v3 vpt = s6lin(velk) + cross(s6ang(velk), x);
+                                contact_apply(Mg, dt, x, vpt, pen, P.n, IA, pA, fsum, P.w);
+                            }
                         }
 #pragma unroll
                         for (int q = 0; q < CO_MAXLEN; ++q) if (k == q) fcon[q] = fsum;

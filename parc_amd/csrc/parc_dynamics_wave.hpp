@@ -79,8 +79,8 @@ struct WaveTables {
     float brad[DYN_MAXB];
     float bc[DYN_MAXB][3], brho[DYN_MAXB];  // bounding sphere of a body's collision spheres (body frame): centre = middle of the
                                             // centres' box, radius includes the sphere radii
-    int fac_off[1 + WV_MAXLIMB][WV_MAXLEN]; // first LDS slot of a body's joint-space factors (spherical 21, hinge 7, fixed / root 0)
-    int fac_total;                          // slots in use (humanoid: 196)
+    int man_base[WV_MAXLIMB], man_cap[WV_MAXLIMB]; // per wave: first LDS slot and LDS share of its contact-plane list (WvMan), in proportion to the
+                                                   // candidates (points + segments) of the bodies it discovers: its limb + the trunk records it prepares
 };
 
 // LDS layout (floats); everything is [slot][64 lanes]
@@ -90,8 +90,7 @@ struct WaveTables {
 #define WV_OFF_ROOTP (WV_OFF_ATTACC + WV_MAXATT * 6 * 64)
 #define WV_OFF_PATCH (WV_OFF_ROOTP + 3 * 64)
 #define WV_OFF_PMAX (WV_OFF_PATCH + DYN_PATCH * DYN_PATCH * 64)
-#define WV_OFF_PMAX3 (WV_OFF_PMAX + WV_PI * WV_PI * 64)
-#define WV_OFF_ROOTI (WV_OFF_PMAX3 + WV_P3 * WV_P3 * 64)
+#define WV_OFF_ROOTI (WV_OFF_PMAX + WV_PI * WV_PI * 64)
 #define WV_OFF_FLAG (WV_OFF_ROOTI + WV_MAXLEN * 30 * 64)   // hand-off flags between the waves of a block (see WV_F_*)
 // A flag holds the number of substeps for which its producer has published: a consumer of substep `sub` waits for > sub.
 #define WV_F_KIN(slot) (12 + (slot)) // wave 0: kinematics of attach slot (0..2) (+ the root position, with the root body's slot)
@@ -99,9 +98,21 @@ struct WaveTables {
 #define WV_F_REC(k) (5 + (k)) // record (own inertia + contacts) of trunk position k (0..2), prepared by wave rec_wave[k]
 #define WV_F_HAND 11           // epilogue: wave 0 has handed the trunk joints' dofs to the helper wave
 #define WV_F_ACC(slot) (8 + (slot)) // wave 0: spatial acceleration of attach slot (0..2)
-#define WV_OFF_FAC (WV_OFF_FLAG + 64)
-#define WV_LDS_FLOATS_MAX (WV_OFF_FAC + (1 + WV_MAXLIMB) * WV_MAXLEN * WV_FAC * 64)
-inline int wv_lds_floats(int fac_total) { return WV_OFF_FAC + fac_total * 64; } // the factor region is last and packed
+// The contact planes of the four waves (WvMan: man_total slots of 8 x 64 floats) take the rest of the CU's LDS.  The 3x3 running maximum of
+// the height patch (the prologue's intermediate for the 5x5 table) is dead after the prologue and aliases the head of that region.  (Round
+// 3 kept the joint-space factors K = U D^-1, D^-1 u in LDS here, 50 KB: they are register arrays now -- a lane reads back what it wrote --
+// which is what makes the room.)
+#ifdef PARC_TRUNK_FAC_REGS
+#define WV_OFF_MAN (WV_OFF_FLAG + 64)
+#else
+#define WV_OFF_TFAC (WV_OFF_FLAG + 64)                        // wave 0: joint-space factors of trunk positions 1..2
+#define WV_OFF_MAN (WV_OFF_TFAC + (WV_MAXLEN - 1) * WV_FAC * 64)
+#endif
+#define WV_OFF_PMAX3 WV_OFF_MAN
+#define WV_LDS_BYTES (160 * 1024)
+#define WV_MAN_TOTAL ((WV_LDS_BYTES / 4 - WV_OFF_MAN) / (8 * 64))
+static_assert(WV_MAN_TOTAL * 8 * 64 >= WV_P3 * WV_P3 * 64, "the 3x3 table fits the region it aliases");
+inline int wv_lds_floats() { return WV_OFF_MAN + WV_MAN_TOTAL * 8 * 64; }
 
 inline bool build_wave_tables(const DynModel &M, const CoopTables &C, WaveTables &W) {
     memset(&W, 0, sizeof(W));
@@ -155,14 +166,17 @@ inline bool build_wave_tables(const DynModel &M, const CoopTables &C, WaveTables
     for (int k = 1; k < W.len[0]; ++k)
         if (W.rec_wave[k] < 0 && W.att_slot[k] < 0 && root_limb >= 1 && natt < WV_MAXATT) { W.att_slot[k] = natt++; W.rec_wave[k] = root_limb; }
     for (int k = 0; k < W.len[0]; ++k) W.prep[k] = W.rec_wave[k] >= 1 ? 1 : 0;
-    int off = 0;
-    for (int c = 0; c < C.nchain; ++c)
-        for (int k = 0; k < W.len[c]; ++k) {
-            const int b = W.body[c][k], jt = M.jtype[b];
-            W.fac_off[c][k] = off;
-            off += (b == 0) ? 0 : (jt == DJ_SPHERICAL ? WV_FAC : (jt == DJ_HINGE ? 7 : 0));
+    {   // LDS shares of the plane lists: two slots each, the rest in proportion to the candidates a wave discovers
+        int cand[WV_MAXLIMB] = {0, 0, 0, 0}, tot = 0, used = 0;
+        for (int w = 0; w < WV_MAXLIMB; ++w) {
+            if (w < W.nlimb) for (int k = 0; k < W.len[w + 1]; ++k) cand[w] += C.npt[W.body[w + 1][k]] + C.nsg[W.body[w + 1][k]];
+            for (int k = 0; k < W.len[0]; ++k) if (W.rec_wave[k] == w || (w == 0 && W.rec_wave[k] < 0)) cand[w] += C.npt[W.body[0][k]] + C.nsg[W.body[0][k]];
+            tot += cand[w];
         }
-    W.fac_total = off;
+        for (int w = 0; w < WV_MAXLIMB; ++w) { W.man_cap[w] = 2 + (tot > 0 ? (WV_MAN_TOTAL - 2 * WV_MAXLIMB) * cand[w] / tot : 0); used += W.man_cap[w]; }
+        for (int w = 0; used < WV_MAN_TOTAL; w = (w + 1) % WV_MAXLIMB) { ++W.man_cap[w]; ++used; }
+        for (int w = 0, at = 0; w < WV_MAXLIMB; ++w) { W.man_base[w] = at; at += W.man_cap[w]; }
+    }
     for (int b = 0; b < M.B; ++b) {
         WvBodyC &c = W.c[b];
         c.jtype = M.jtype[b]; c.dof_idx = M.dof_idx[b]; c.npt = W.npt[b]; c.pt0 = W.pt0[b];
@@ -183,7 +197,6 @@ inline bool build_wave_tables(const DynModel &M, const CoopTables &C, WaveTables
         W.c[b].nsg = C.nsg[b]; W.c[b].sg0 = C.sg0[b];
         if (C.npt[b] + C.nsg[b] > 32) return false;
     }
-    if (wv_lds_floats(off) * (int)sizeof(float) > 160 * 1024) return false; // does not fit one CU's LDS: the caller falls back to the chain-parallel kernel
     return true;
 }
 
@@ -212,6 +225,9 @@ __device__ unsigned long long g_wave_stamps[4][16];
 __device__ unsigned long long g_wave_cnt[16][8]; // filled by -DPARC_COUNTS builds only, per body: lanes, near lanes (body window reaches down to its 5x5 maximum), waves with a
                                                  // near lane, (lane, candidate) pairs that enter the narrow phase, candidates of the body (points + segments) x waves,
                                                  // slow lanes, narrow-phase executions (a candidate with at least one lane), waves
+__device__ unsigned long long g_wave_hist[16][4][16]; // -DPARC_COUNTS: substep 0, per body (15 = the wave's whole limb): histogram of the wave-maximum of the per-lane
+                                                      // count of [0] flat contacts (point candidate, normal +z), [1] generic contacts, [2] both, within the speculative margin;
+                                                      // [3][0..2] = sums over lanes of flat / generic / lanes
 #define WSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); wacc[i] += t_ - wlast; wlast = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
 // pin: the 27 values of (IA, pA) must be complete before the stamp that follows (keeps arithmetic from sinking past it)
 #define WPIN(IA_, pA_) do { for (int i_ = 0; i_ < 21; ++i_) asm volatile("" : "+v"((IA_).s[i_])); for (int i_ = 0; i_ < 6; ++i_) asm volatile("" : "+v"((pA_).a[i_])); } while (0)
@@ -276,6 +292,16 @@ struct WvCtx { // per-lane constants of the control step
                               // reference's env-local coordinates reach ~1 km at 65 536 envs (ulp 6e-5 m), see the kernel prologue.
 };
 
+// The wave's per-lane list of contact planes (parc_dynamics.hpp, contact manifold).  A plane is 8 floats (body-frame point, world normal,
+// offset in the patch frame, weight), laid out [slot][field][lane]; slots [0, cap) live in LDS, the next WV_MAN_OVF in global memory (the
+// lane's overflow area: only lanes with more planes than the wave's LDS share touch it), anything beyond is dropped and counted in
+// g_wave_man_drops (parc_env_dynamics_manifold_drops: must stay 0, the GPU tests check it).  The list is filled body by body in the order
+// the wave visits its bodies (`site` = the static index of the visit: records 0..2, limb bodies 3..5, wave 0's own trunk bodies 6..8) and
+// walked in the same order in every substep: `cur` is the running start of the current body, `cnt` holds the per-site counts (6 bits each).
+#define WV_MAN_OVF 12
+struct WvMan { float *lds, *glb; int cap, cur; unsigned long long cnt; };
+__device__ unsigned int g_wave_man_drops;
+
 // a contact with a general normal: the shared statement of parc_dynamics.hpp
 __device__ __forceinline__ void wv_contact_generic(const DynModel &M, float dt, v3 x, v3 vpt, float pen, v3 n, sym6 &IA, s6 &pA, v3 &fsum, float w) {
     contact_apply(M, dt, x, vpt, pen, n, IA, pA, fsum, w);
@@ -307,7 +333,7 @@ __device__ __forceinline__ void wv_point_apply(float dt, v3 x, v3 F, const float
 
 // articulated inertia / bias of body b: own inertia + contacts + (IA, pA) carried in from the chain's child
 __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTables &W, const DynTerrain &T, const WvCtx &X, int b, WvBody &B,
-                                                const m3 &R, v3 rootp, sym6 &IA, s6 &pA WSTAMP_PARAMS) {
+                                                const m3 &R, v3 rootp, sym6 &IA, s6 &pA, WvMan &man, const int site, const bool discover WSTAMP_PARAMS) {
     const v3 r = B.r;
     const float dt = X.dt;
     const DynTerrain &Tp = X.Tp;
@@ -342,217 +368,235 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
     }
     WPIN(IA, pA);
     WSTAMP(12);
-    // contacts.  A body whose bounding sphere clears every column its collision spheres could touch is skipped
-    // (exact: those contributions are zero).  The sphere centres lie within brho of the bounding centre, i.e. (brho < one
-    // cell) in the 3x3 cells around its cell, and each touches at most the columns one cell further: the 5x5 window.
-    v3 fsum = mk(0.f, 0.f, 0.f);
-    const float brho = W.c[b].brho;
-    float hmax = 3.0e38f; // highest column any sphere of this body can touch (+inf when the 5x5 window is not applicable)
-    {
-        const v3 cb = r + mulv(R, mk(W.c[b].bc[0], W.c[b].bc[1], W.c[b].bc[2]));
-        const int bx = cell_of(cb.x + rootp.x, Tp.min_x, Tp.dx), by = cell_of(cb.y + rootp.y, Tp.min_y, Tp.dy);
-        if (brho < X.cell_min && bx >= 2 && bx < DYN_PATCH - 2 && by >= 2 && by < DYN_PATCH - 2) {
-            hmax = X.s_pmax[((bx - 2) * WV_PI + by - 2) * 64];
-            if (cb.z + rootp.z - brho > hmax) hmax = -3.0e38f; // clears everything: no point survives the test below
-        }
-    }
-    // Narrow phase.  A sphere can only touch the column of its own cell and the columns of the neighbours on the sides whose face is
-    // closer than its radius (for rad < half a cell: at most the x-side, the y-side and their diagonal; the far sides are at least half a
-    // cell away); whether a candidate is a contact stays with sphere_vs_column / the penetration sign, so the result equals the exhaustive
-    // 9-column test of parc_dynamics.hpp.  Per lane a sphere is only culled against the 5x5 maximum of its body (hmax).  Rounds 1-2 ran a
-    // cull pass per point first (a look-up of the 3x3 running maximum around the sphere's cell, a hit bit per point): with lane = env a
-    // wave executes the narrow phase of a point as soon as ONE of its 64 envs needs it, and that was measured to be the case for every
-    // point of every body in every wave (tools/wave_stamps.py, round 3) -- the pass culled nothing at wave level and cost 11 % of the
-    // kernel; without it 0.493 -> 0.478 ms at 65 536 envs.
-    // Lanes with a point outside the staged patch (or a sphere wider than a cell) take the exhaustive path below.
-    const int npt = W.c[b].npt, pt0 = W.c[b].pt0, nsg = W.c[b].nsg, sg0 = W.c[b].sg0;
-    const float hx = 0.5f * Tp.dx, hy = 0.5f * Tp.dy;
-    bool slow = false;
-#ifdef PARC_COUNTS
-    int cnt_pairs = 0, cnt_exec = 0; // wave-uniform
-#endif
-    // edge candidate of segment ks (patch frame).  FAST: heights from the staged patch with clamped indices -- both ends of a segment are
-    // collision points of the body, so a lane whose segment leaves the inner patch is a `slow` lane below, which uses the other variant
-    // (global memory outside the patch)
-    auto seg_ends = [&](int ks, v3 &A, v3 &Bv) __attribute__((always_inline)) {
-        A = r + mulv(R, mk(W.seg[ks][0], W.seg[ks][1], W.seg[ks][2])) + rootp;
-        Bv = r + mulv(R, mk(W.seg[ks][4], W.seg[ks][5], W.seg[ks][6])) + rootp;
-    };
-    auto seg_point = [&](int ks, v3 &Q) __attribute__((always_inline)) {
-        v3 A, Bv;
-        seg_ends(ks, A, Bv);
-        return segment_edge_point(Tp, A, Bv, [&](int ix, int iy) {
-            const int a_ = ix < 0 ? 0 : (ix > DYN_PATCH - 1 ? DYN_PATCH - 1 : ix), b_ = iy < 0 ? 0 : (iy > DYN_PATCH - 1 ? DYN_PATCH - 1 : iy);
-            return X.s_patch[(a_ * DYN_PATCH + b_) * 64]; }, Q);
-    };
-    auto seg_point_slow = [&](int ks, v3 &Q) __attribute__((always_inline)) {
-        v3 A, Bv;
-        seg_ends(ks, A, Bv);
-        return segment_edge_point(Tp, A, Bv, [&](int ix, int iy) {
-            return (ix >= 0 && ix < DYN_PATCH && iy >= 0 && iy < DYN_PATCH) ? X.s_patch[(ix * DYN_PATCH + iy) * 64] : hf_at(T, X.pox + ix, X.poy + iy); }, Q);
-    };
-    // Which lanes take the straight path: the body's 5x5 window is applicable (all its spheres then lie in the inner patch) and every
-    // sphere is narrower than half a cell.  The others take the exhaustive path further down.
-    {
-        const float fast_r = X.cell_min * 0.5f - 2e-3f;
-        bool wide = false;
-        for (int pi = 0; pi < npt; ++pi) wide = wide || !(W.colp[pt0 + pi][3] < fast_r); // uniform
-        slow = (hmax > 1.0e38f) || (wide && hmax > -1.0e38f);
-    }
-    WPIN(IA, pA);
-    WSTAMP(4);  // body test
-    // narrow phase of one candidate sphere (centre x relative to O, g = x + rootp in the patch frame) of a lane whose spheres all lie in
-    // the inner patch: own column, then the neighbour columns on the sides whose face is closer than the radius.
-    // All contacts of one sphere act at the same point x, so they are first summed in POINT space -- force F and the 3x3 matrix
-    // Bm = sum beta 1 + (bn - beta) n n^T of the implicit term -- and mapped into the body's 6x6 once (wv_point_apply): one application per
-    // candidate instead of one per contact and per branch.  With lane = env a wave executes every branch some lane takes, and at 64 envs
-    // that is all of them (measured: every point of every body reaches this code in every wave), so the saving is in code that always runs.
-    // Mathematically the sum of contact_apply over the contacts (parc_dynamics.hpp); it rounds differently.
-    auto narrow = [&](v3 x, v3 g, float rad, float w) __attribute__((always_inline)) {
-        const float zlo = g.z - rad;
-        const int pa_ = cell_of(g.x, Tp.min_x, Tp.dx), pb_ = cell_of(g.y, Tp.min_y, Tp.dy); // patch indices = cell indices of the patch frame
-        const float ex = g.x - (Tp.min_x + (float)pa_ * Tp.dx), ey = g.y - (Tp.min_y + (float)pb_ * Tp.dy);
-        const int sx = ex >= 0.f ? 1 : -1, sy = ey >= 0.f ? 1 : -1;
-        // every height this candidate can ask for -- own cell, the four face neighbours, the diagonal on the centre's side -- is requested
-        // up front: six LDS reads in flight together instead of up to eight dependent round trips (one resident wave per SIMD: nothing
-        // else hides them)
-        const float *hp = X.s_patch + (pa_ * DYN_PATCH + pb_) * 64;
-        float top0 = hp[0], hxp = hp[DYN_PATCH * 64], hxm = hp[-DYN_PATCH * 64], hyp = hp[64], hym = hp[-64], hd = hp[(sx * DYN_PATCH + sy) * 64];
-        asm volatile("" : "+v"(top0), "+v"(hxp), "+v"(hxm), "+v"(hyp), "+v"(hym), "+v"(hd));
-        const v3 vpt = s6lin(B.vel) + cross(s6ang(B.vel), x);
-        v3 F = mk(0.f, 0.f, 0.f);
-        float Bm[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; // xx yy zz xy xz yz
-        auto acc = [&](float pen, v3 n) __attribute__((always_inline)) { // contact_apply's force law, accumulated in point space
-            const bool capped = pen > M.pen_cap;
-            if (capped) pen = M.pen_cap;
-            const float vn = dot(vpt, n);
-            float fn = w * (M.kn * pen - M.dn * vn);
-            if (fn < 0.f) fn = 0.f;
-            const v3 vt = vpt - vn * n;
-            const float vtm = DYN_SQRT(dot(vt, vt));
-            float beta = w * M.dtang;
-            if (beta * vtm > M.mu * fn) beta = vtm > 1e-9f ? M.mu * fn * DYN_RCP(vtm) : 0.f;
-            F = F + (fn * n - beta * vt);
-            const float bn = fn > 0.f ? w * (M.dn + (capped ? 0.f : dt * M.kn)) : 0.f;
-            const float k = bn - beta;
-            Bm[0] += beta + k * n.x * n.x; Bm[1] += beta + k * n.y * n.y; Bm[2] += beta + k * n.z * n.z;
-            Bm[3] += k * n.x * n.y; Bm[4] += k * n.x * n.z; Bm[5] += k * n.y * n.z;
-        };
-        bool touched = false;
-        {   // own column: centre above the surface -> normal +z; centre inside the solid -> cheapest way out (own_column_contact)
-            v3 n = mk(0.f, 0.f, 1.f);
-            float pen = rad + top0 - g.z;
-            if (g.z < top0) pen = own_column_contact(Tp, g, rad, pa_, pb_, top0, [&](int ox, int oy) { return ox == 1 ? hxp : (ox == -1 ? hxm : (oy == 1 ? hyp : hym)); }, n);
-            if (pen > 0.f) { acc(pen, n); touched = true; }
-        }
-        const float lim = rad + 1e-3f; // slack >> the rounding of the cell centres: it only admits candidates
-        // (a point of radius 0 -- a box corner -- cannot touch a neighbour column at all: pen = -distance.  `rad` is wave-uniform, so the
-        // whole neighbour block is a scalar branch for the 16 foot corners)
-        const bool nx = rad > 0.f && hx - fabsf(ex) < lim, ny = rad > 0.f && hy - fabsf(ey) < lim;
-        if (nx || ny) {
-            for (int c = 0; c < 3; ++c) { // x side, y side, diagonal
-                const bool want = c == 0 ? nx : (c == 1 ? ny : (nx && ny));
-                if (!want) continue;
-                const int ox_ = c == 1 ? 0 : sx, oy_ = c == 0 ? 0 : sy;
-                const float top = c == 0 ? (sx > 0 ? hxp : hxm) : (c == 1 ? (sy > 0 ? hyp : hym) : hd);
-                if (!(top > top0 + 1e-3f) || zlo > top) continue; // only higher neighbours act as walls / step edges
-                v3 n;
-                const float pen = sphere_vs_column(Tp, g, rad, pa_ + ox_, pb_ + oy_, top, n);
-                if (pen > 0.f) { acc(pen, n); touched = true; }
+    // Contacts (parc_dynamics.hpp, contact manifold): DISCOVERY in the substeps 0, man_period, ... -- every candidate sphere of the body
+    // against the columns it can reach within the speculative margin -> planes in this wave's per-lane list --, then, in EVERY substep, the
+    // EVALUATION of the body's planes.  With lane = env a wave executes the narrow phase of a candidate as soon as ONE of its 64 envs needs
+    // it (round 3: every candidate of every body, in every wave), so the discovery costs what the whole contact code cost in round 3; the
+    // evaluation loop's trip count is the LARGEST per-lane plane count of the body in the wave (feet: 4-8 of 10 candidates x 4 columns).
+    const int site6 = 6 * site;
+    if (discover) {
+        // A body whose bounding sphere (+ the largest margin) clears every column its collision spheres could touch is skipped (exact:
+        // nothing is emitted).  The sphere centres lie within brho of the bounding centre, i.e. (brho < one cell) in the 3x3 cells around
+        // its cell, and each touches at most the columns one cell further: the 5x5 window.
+        const float brho = W.c[b].brho;
+        const float smax = M.spec_max;
+        float hmax = 3.0e38f; // highest column any sphere of this body can touch (+inf when the 5x5 window is not applicable)
+        {
+            const v3 cb = r + mulv(R, mk(W.c[b].bc[0], W.c[b].bc[1], W.c[b].bc[2]));
+            const int bx = cell_of(cb.x + rootp.x, Tp.min_x, Tp.dx), by = cell_of(cb.y + rootp.y, Tp.min_y, Tp.dy);
+            if (brho < X.cell_min && bx >= 2 && bx < DYN_PATCH - 2 && by >= 2 && by < DYN_PATCH - 2) {
+                hmax = X.s_pmax[((bx - 2) * WV_PI + by - 2) * 64];
+                if (cb.z + rootp.z - brho - smax > hmax) hmax = -3.0e38f; // clears everything: no point survives the test below
             }
         }
-        if (touched) wv_point_apply(dt, x, F, Bm, IA, pA, fsum);
-    };
-    {   // the table entry of the NEXT point is requested while this one is processed (a scalar load waited for at the top of every
-        // iteration is a ~200-cycle stall with one resident wave per SIMD)
-        struct ColPt2 { float x, y, z, r; };
-        auto load_pt2 = [&](int pi) __attribute__((always_inline)) {
-            const int kp = pt0 + (pi < npt ? pi : 0);
-            ColPt2 c; c.x = W.colp[kp][0]; c.y = W.colp[kp][1]; c.z = W.colp[kp][2]; c.r = W.colp[kp][3];
-            return c;
-        };
-        ColPt2 cur = load_pt2(0);
-        for (int pi = 0; pi < npt; ++pi) {
-            const ColPt2 nxt = load_pt2(pi + 1);
-            const v3 x = r + mulv(R, mk(cur.x, cur.y, cur.z));
-            const v3 g = x + rootp;
-            const bool mine = !slow && !(g.z - cur.r > hmax); // the sphere reaches down to the highest column of the body's window
+        // Narrow phase.  A sphere can only come within the margin of the column of its own cell and of the neighbours on the sides whose
+        // face is closer than radius + margin (for rad + spec_max < half a cell: at most the x-side, the y-side and their diagonal; the far
+        // sides are at least half a cell away); whether a candidate is emitted stays with sphere_vs_column / own_column_contact and the
+        // margin test, so the result equals sphere_discover's exhaustive 9-column test (parc_dynamics.hpp).  Lanes with a point outside the
+        // staged patch (or a sphere too wide for the near-side argument) take that exhaustive path below.
+        const int npt = W.c[b].npt, pt0 = W.c[b].pt0, nsg = W.c[b].nsg, sg0 = W.c[b].sg0;
+        const float hx = 0.5f * Tp.dx, hy = 0.5f * Tp.dy;
+        bool slow = false;
+        int n_new = 0; // planes this lane has pushed for the body
 #ifdef PARC_COUNTS
-            cnt_pairs += __popcll(__ballot(mine)); cnt_exec += __any(mine) ? 1 : 0;
+        int cnt_pairs = 0, cnt_exec = 0; // wave-uniform
 #endif
-            if (__any(mine)) { // uniform
-                if (mine) narrow(x, g, cur.r, 1.f);
-            }
-            cur = nxt;
-        }
-    }
-    WPIN(IA, pA);
-    WSTAMP(13); // narrow phase of the collision points
-    // The body's segments: where a shaft / sole edge crosses a grid line with a step, the closest point to that edge is one more candidate
-    // sphere (segment_edge_point, parc_dynamics.hpp).  No cull pass of its own: at wave level some lane nearly always has a candidate
-    // (measured), so the candidate is formed once and goes straight to the narrow phase, which is exact by itself.
-    if (__any(hmax > -1.0e38f)) {
-        for (int si = 0; si < nsg; ++si) {
-            v3 Q = rootp;
-            const float wq = seg_point(sg0 + si, Q);
-            const bool has = wq > 0.f && !slow && !(Q.z - W.seg[sg0 + si][3] > hmax);
-#ifdef PARC_COUNTS
-            cnt_pairs += __popcll(__ballot(has)); cnt_exec += __any(has) ? 1 : 0;
-#endif
-            if (!__any(has)) continue; // uniform
-            if (has) narrow(Q - rootp, Q, W.seg[sg0 + si][3], wq);
-        }
-    }
-    if (slow) { // exhaustive test of every candidate, heights from the patch where it covers them, else from global memory
-        for (int pi = 0; pi < npt + nsg; ++pi) {
-            v3 x; float rad, wq = 1.f;
-            if (pi < npt) {
-                const int kp = pt0 + pi;
-                x = r + mulv(R, mk(W.colp[kp][0], W.colp[kp][1], W.colp[kp][2]));
-                rad = W.colp[kp][3];
+        // one plane into the lane's list: LDS slots [0, cap), then the overflow area in global memory, then dropped (counted)
+        auto push = [&](v3 pb, v3 n, float off, float wq) __attribute__((always_inline)) {
+            const int slot = man.cur + n_new;
+            if (slot < man.cap) {
+                float *e_ = man.lds + slot * (8 * 64);
+                e_[0] = pb.x; e_[64] = pb.y; e_[128] = pb.z; e_[192] = n.x; e_[256] = n.y; e_[320] = n.z; e_[384] = off; e_[448] = wq;
+                ++n_new;
+            } else if (slot < man.cap + WV_MAN_OVF) {
+                float *e_ = man.glb + (slot - man.cap) * (8 * 64);
+                e_[0] = pb.x; e_[64] = pb.y; e_[128] = pb.z; e_[192] = n.x; e_[256] = n.y; e_[320] = n.z; e_[384] = off; e_[448] = wq;
+                ++n_new;
             } else {
-                v3 Q = rootp;
-                wq = seg_point_slow(sg0 + pi - npt, Q);
-                if (!(wq > 0.f)) continue;
-                x = Q - rootp; rad = W.seg[sg0 + pi - npt][3];
+                atomicAdd(&g_wave_man_drops, 1u);
             }
-            const v3 g = x + rootp;
-            const float zlo = g.z - rad;
-            if (zlo > hmax) continue;
-            const int pa_ = cell_of(g.x, Tp.min_x, Tp.dx), pb_ = cell_of(g.y, Tp.min_y, Tp.dy);
-            const int ix = X.pox + pa_, iy = X.poy + pb_; // global cell (heights outside the patch come from global memory)
-            const bool inp = pa_ >= 1 && pa_ < DYN_PATCH - 1 && pb_ >= 1 && pb_ < DYN_PATCH - 1;
-            const float top0 = inp ? X.s_patch[(pa_ * DYN_PATCH + pb_) * 64] : hf_at(T, ix, iy);
+        };
+        auto seg_ends = [&](int ks, v3 &A, v3 &Bv) __attribute__((always_inline)) {
+            A = r + mulv(R, mk(W.seg[ks][0], W.seg[ks][1], W.seg[ks][2])) + rootp;
+            Bv = r + mulv(R, mk(W.seg[ks][4], W.seg[ks][5], W.seg[ks][6])) + rootp;
+        };
+        // edge candidate of segment ks (patch frame).  FAST: heights from the staged patch with clamped indices -- both ends of a segment
+        // are collision points of the body, so a lane whose segment leaves the inner patch is a `slow` lane, which uses the other variant
+        // (global memory outside the patch)
+        auto seg_point = [&](int ks, v3 &Q) __attribute__((always_inline)) {
+            v3 A, Bv;
+            seg_ends(ks, A, Bv);
+            return segment_edge_point(Tp, A, Bv, [&](int ix, int iy) {
+                const int a_ = ix < 0 ? 0 : (ix > DYN_PATCH - 1 ? DYN_PATCH - 1 : ix), b_ = iy < 0 ? 0 : (iy > DYN_PATCH - 1 ? DYN_PATCH - 1 : iy);
+                return X.s_patch[(a_ * DYN_PATCH + b_) * 64]; }, Q);
+        };
+        auto top_slow = [&](int ix, int iy) __attribute__((always_inline)) {
+            return (ix >= 0 && ix < DYN_PATCH && iy >= 0 && iy < DYN_PATCH) ? X.s_patch[(ix * DYN_PATCH + iy) * 64] : hf_at(T, X.pox + ix, X.poy + iy); };
+        auto seg_point_slow = [&](int ks, v3 &Q) __attribute__((always_inline)) {
+            v3 A, Bv;
+            seg_ends(ks, A, Bv);
+            return segment_edge_point(Tp, A, Bv, top_slow, Q);
+        };
+        // Which lanes take the straight path: the body's 5x5 window is applicable (all its spheres then lie in the inner patch) and every
+        // sphere + margin is narrower than half a cell.  The others take the exhaustive path further down.
+        {
+            const float fast_r = X.cell_min * 0.5f - 2e-3f - smax;
+            bool wide = false;
+            for (int pi = 0; pi < npt; ++pi) wide = wide || !(W.colp[pt0 + pi][3] < fast_r); // uniform
+            slow = (hmax > 1.0e38f) || (wide && hmax > -1.0e38f);
+        }
+        // narrow phase of one candidate sphere (body-frame centre pb, x relative to O, g = x + rootp in the patch frame) of a lane whose
+        // spheres all lie in the inner patch: own column, then the neighbour columns on the sides whose face is closer than radius + margin
+        auto narrow = [&](v3 pb, v3 x, v3 g, float rad, float wq) __attribute__((always_inline)) {
+            const int pa_ = cell_of(g.x, Tp.min_x, Tp.dx), pb_ = cell_of(g.y, Tp.min_y, Tp.dy); // patch indices = cell indices of the patch frame
+            const float ex = g.x - (Tp.min_x + (float)pa_ * Tp.dx), ey = g.y - (Tp.min_y + (float)pb_ * Tp.dy);
+            const int sx = ex >= 0.f ? 1 : -1, sy = ey >= 0.f ? 1 : -1;
+            // every height this candidate can ask for -- own cell, the four face neighbours, the diagonal on the centre's side -- is requested
+            // up front: six LDS reads in flight together instead of up to eight dependent round trips
+            const float *hp = X.s_patch + (pa_ * DYN_PATCH + pb_) * 64;
+            float top0 = hp[0], hxp = hp[DYN_PATCH * 64], hxm = hp[-DYN_PATCH * 64], hyp = hp[64], hym = hp[-64], hd = hp[(sx * DYN_PATCH + sy) * 64];
+            asm volatile("" : "+v"(top0), "+v"(hxp), "+v"(hxm), "+v"(hyp), "+v"(hym), "+v"(hd));
             const v3 vpt = s6lin(B.vel) + cross(s6ang(B.vel), x);
-            for (int nb = 0; nb < 9; ++nb) {
-                const int ox_ = (nb % 3) - 1, oy_ = (nb / 3) - 1;
-                const float top = nb == 4 ? top0 : (inp ? X.s_patch[((pa_ + ox_) * DYN_PATCH + pb_ + oy_) * 64] : hf_at(T, ix + ox_, iy + oy_));
-                if (!(nb == 4 || top > top0 + 1e-3f) || zlo > top) continue;
-                v3 n;
-                const float pen = nb == 4 ? own_column_contact(Tp, g, rad, pa_, pb_, top0, [&](int ox, int oy) {
-                                                return inp ? X.s_patch[((pa_ + ox) * DYN_PATCH + pb_ + oy) * 64] : hf_at(T, ix + ox, iy + oy); }, n)
-                                          : sphere_vs_column(Tp, g, rad, pa_ + ox_, pb_ + oy_, top, n);
-                if (pen > 0.f) wv_contact_generic(M, dt, x, vpt, pen, n, IA, pA, fsum, wq);
+            const float zlo = g.z - rad - spec_margin(M, vpt.z);
+            if (!(zlo > top0)) { // own column: centre above the surface -> normal +z; centre inside the solid -> cheapest way out (own_column_contact)
+                v3 n = mk(0.f, 0.f, 1.f);
+                float pen = rad + top0 - g.z;
+                if (g.z < top0) pen = own_column_contact(Tp, g, rad, pa_, pb_, top0, [&](int ox, int oy) { return ox == 1 ? hxp : (ox == -1 ? hxm : (oy == 1 ? hyp : hym)); }, n);
+                if (pen > -spec_margin(M, dot(vpt, n))) push(pb, n, pen + dot(n, g), wq);
+            }
+            const float lim = rad + smax + 1e-3f; // slack >> the rounding of the cell centres: it only admits candidates
+            const bool nx = hx - fabsf(ex) < lim, ny = hy - fabsf(ey) < lim;
+            if (nx || ny) {
+                for (int c = 0; c < 3; ++c) { // x side, y side, diagonal
+                    const bool want = c == 0 ? nx : (c == 1 ? ny : (nx && ny));
+                    if (!want) continue;
+                    const int ox_ = c == 1 ? 0 : sx, oy_ = c == 0 ? 0 : sy;
+                    const float top = c == 0 ? (sx > 0 ? hxp : hxm) : (c == 1 ? (sy > 0 ? hyp : hym) : hd);
+                    if (!(top > top0 + 1e-3f) || zlo > top) continue; // only higher neighbours act as walls / step edges
+                    v3 n;
+                    const float pen = sphere_vs_column(Tp, g, rad, pa_ + ox_, pb_ + oy_, top, n);
+                    if (pen > -spec_margin(M, dot(vpt, n))) push(pb, n, pen + dot(n, g), wq);
+                }
+            }
+        };
+        {   // the table entry of the NEXT point is requested while this one is processed (a scalar load waited for at the top of every
+            // iteration is a ~200-cycle stall with one resident wave per SIMD)
+            struct ColPt2 { float x, y, z, r; };
+            auto load_pt2 = [&](int pi) __attribute__((always_inline)) {
+                const int kp = pt0 + (pi < npt ? pi : 0);
+                ColPt2 c; c.x = W.colp[kp][0]; c.y = W.colp[kp][1]; c.z = W.colp[kp][2]; c.r = W.colp[kp][3];
+                return c;
+            };
+            ColPt2 cur = load_pt2(0);
+            for (int pi = 0; pi < npt; ++pi) {
+                const ColPt2 nxt = load_pt2(pi + 1);
+                const v3 pb = mk(cur.x, cur.y, cur.z);
+                const v3 x = r + mulv(R, pb);
+                const v3 g = x + rootp;
+                const bool mine = !slow && !(g.z - cur.r - smax > hmax); // the sphere reaches down to the highest column of the body's window
+#ifdef PARC_COUNTS
+                cnt_pairs += __popcll(__ballot(mine)); cnt_exec += __any(mine) ? 1 : 0;
+#endif
+                if (__any(mine)) { // uniform
+                    if (mine) narrow(pb, x, g, cur.r, 1.f);
+                }
+                cur = nxt;
             }
         }
+        WPIN(IA, pA);
+        WSTAMP(13); // narrow phase of the collision points
+        // The body's segments: where a shaft / sole edge crosses a grid line with a step, the closest point to that edge is one more candidate
+        // sphere (segment_edge_point, parc_dynamics.hpp), kept in the body frame like a point's centre.
+        if (__any(hmax > -1.0e38f)) {
+            for (int si = 0; si < nsg; ++si) {
+                v3 Q = rootp;
+                const float wq = seg_point(sg0 + si, Q);
+                const bool has = wq > 0.f && !slow && !(Q.z - W.seg[sg0 + si][3] - smax > hmax);
+#ifdef PARC_COUNTS
+                cnt_pairs += __popcll(__ballot(has)); cnt_exec += __any(has) ? 1 : 0;
+#endif
+                if (!__any(has)) continue; // uniform
+                if (has) { const v3 x = Q - rootp; narrow(mulTv(R, x - r), x, Q, W.seg[sg0 + si][3], wq); }
+            }
+        }
+        if (slow) { // exhaustive test of every candidate, heights from the patch where it covers them, else from global memory
+            for (int pi = 0; pi < npt + nsg; ++pi) {
+                v3 x, pb; float rad, wq = 1.f;
+                if (pi < npt) {
+                    const int kp = pt0 + pi;
+                    pb = mk(W.colp[kp][0], W.colp[kp][1], W.colp[kp][2]);
+                    x = r + mulv(R, pb);
+                    rad = W.colp[kp][3];
+                } else {
+                    v3 Q = rootp;
+                    wq = seg_point_slow(sg0 + pi - npt, Q);
+                    if (!(wq > 0.f)) continue;
+                    x = Q - rootp; rad = W.seg[sg0 + pi - npt][3];
+                    pb = mulTv(R, x - r);
+                }
+                const v3 g = x + rootp;
+                if (g.z - rad - smax > hmax) continue;
+                const v3 vpt = s6lin(B.vel) + cross(s6ang(B.vel), x);
+                sphere_discover(M, Tp, g, rad, vpt, top_slow, [&](float pen, v3 n) { push(pb, n, pen + dot(n, g), wq); });
+            }
+        }
+        man.cnt = (man.cnt & ~(63ull << site6)) | ((unsigned long long)n_new << site6);
+#ifdef PARC_COUNTS
+        {
+            const unsigned long long m_near = __ballot(hmax > -1.0e38f), m_slow = __ballot(slow);
+            if ((threadIdx.x & 63) == 0) {
+                atomicAdd(&g_wave_cnt[b][0], 64ull); atomicAdd(&g_wave_cnt[b][1], (unsigned long long)__popcll(m_near));
+                atomicAdd(&g_wave_cnt[b][2], m_near ? 1ull : 0ull); atomicAdd(&g_wave_cnt[b][3], (unsigned long long)cnt_pairs);
+                atomicAdd(&g_wave_cnt[b][4], (unsigned long long)(npt + nsg)); atomicAdd(&g_wave_cnt[b][5], (unsigned long long)__popcll(m_slow));
+                atomicAdd(&g_wave_cnt[b][6], (unsigned long long)cnt_exec); atomicAdd(&g_wave_cnt[b][7], 1ull);
+            }
+        }
+#endif
+        WPIN(IA, pA);
+        WSTAMP(6);  // segments (+ the exhaustive path of lanes outside the patch)
+    }
+    // ---- evaluation of the body's planes: x = r + R p, pen = off - n . (x + rootp); contact_apply on pen > 0 (the shared statement of
+    // parc_dynamics.hpp).  Slots [cur, cur + n) of the lane's list; the trip count is the largest n in the wave.
+    v3 fsum = mk(0.f, 0.f, 0.f);
+    {
+        const int n_me = (int)((man.cnt >> site6) & 63ull);
+        for (int t = 0; __any(t < n_me); ++t) {
+            const bool act = t < n_me;
+            const int slot = act ? man.cur + t : 0;
+            const bool inl = slot < man.cap;
+            float e_[8];
+            {
+                const float *q_ = man.lds + (inl ? slot : 0) * (8 * 64);
+                PARC_UNROLL
+                for (int f = 0; f < 8; ++f) e_[f] = q_[f * 64];
+            }
+            if (__any(!inl)) { // overflow area (rare): the lane's own earlier stores, global memory
+                if (!inl) {
+                    const float *q_ = man.glb + (slot - man.cap) * (8 * 64);
+                    PARC_UNROLL
+                    for (int f = 0; f < 8; ++f) e_[f] = __builtin_nontemporal_load(q_ + f * 64);
+                }
+            }
+            const v3 x = r + mulv(R, mk(e_[0], e_[1], e_[2]));
+            const v3 n = mk(e_[3], e_[4], e_[5]);
+            const float pen = e_[6] - dot(n, x + rootp);
+            const bool hit = act && pen > 0.f;
+            if (__any(hit)) {
+                if (hit) {
+                    const v3 vpt = s6lin(B.vel) + cross(s6ang(B.vel), x);
+                    contact_apply(M, dt, x, vpt, pen, n, IA, pA, fsum, e_[7]);
+                }
+            }
+        }
+        man.cur += n_me;
     }
     B.fcon = fsum;
-#ifdef PARC_COUNTS
-    {
-        const unsigned long long m_near = __ballot(hmax > -1.0e38f), m_slow = __ballot(slow);
-        if ((threadIdx.x & 63) == 0) {
-            atomicAdd(&g_wave_cnt[b][0], 64ull); atomicAdd(&g_wave_cnt[b][1], (unsigned long long)__popcll(m_near));
-            atomicAdd(&g_wave_cnt[b][2], m_near ? 1ull : 0ull); atomicAdd(&g_wave_cnt[b][3], (unsigned long long)cnt_pairs);
-            atomicAdd(&g_wave_cnt[b][4], (unsigned long long)(npt + nsg)); atomicAdd(&g_wave_cnt[b][5], (unsigned long long)__popcll(m_slow));
-            atomicAdd(&g_wave_cnt[b][6], (unsigned long long)cnt_exec); atomicAdd(&g_wave_cnt[b][7], 1ull);
-        }
-    }
-#endif
     WPIN(IA, pA);
-    WSTAMP(6);  // segments (+ the exhaustive path of lanes outside the patch)
+    WSTAMP(4);  // evaluation of the body's planes
 }
 
-// joint elimination of body b: (IA, pA) -> contribution (Ic, pc) to the parent; K and D^-1 u go to LDS (fac + lane, stride 64)
+// joint elimination of body b: (IA, pA) -> contribution (Ic, pc) to the parent; K and D^-1 u stay in `fac` (registers) for the outward pass
+template <int FS> // FS: stride of `fac` (1: a register array; 64: [slot][lane] in LDS)
 __device__ __forceinline__ void wv_joint_inward(const DynModel &M, const WaveTables &W, int b, const WvBody &B, const m3 &R, float dt, const sym6 &IA, const s6 &pA,
                                                 sym6 &Ic, s6 &pc, float *fac) {
     const int jt = W.c[b].jtype, di = W.c[b].dof_idx;
@@ -622,8 +666,8 @@ __device__ __forceinline__ void wv_joint_inward(const DynModel &M, const WaveTab
         PARC_UNROLL
         for (int q = 0; q < 3; ++q) {
             PARC_UNROLL
-            for (int a = 0; a < 6; ++a) fac[(6 * q + a) * 64] = Kc[q].a[a];
-            fac[(18 + q) * 64] = du[q];
+            for (int a = 0; a < 6; ++a) fac[(6 * q + a) * FS] = Kc[q].a[a];
+            fac[(18 + q) * FS] = du[q];
         }
     } else if (jt == DJ_HINGE) {
         const v3 a = mulv(R, mk(W.c[b].axis[0], W.c[b].axis[1], W.c[b].axis[2]));
@@ -649,8 +693,8 @@ __device__ __forceinline__ void wv_joint_inward(const DynModel &M, const WaveTab
         }
         const s6 Iac = symmul(Ic, B.cJ);
         PARC_UNROLL
-        for (int q = 0; q < 6; ++q) { pc.a[q] = pA.a[q] + Iac.a[q] + Kc.a[q] * uu; fac[q * 64] = Kc.a[q]; }
-        fac[6 * 64] = di_ * uu;
+        for (int q = 0; q < 6; ++q) { pc.a[q] = pA.a[q] + Iac.a[q] + Kc.a[q] * uu; fac[q * FS] = Kc.a[q]; }
+        fac[6 * FS] = di_ * uu;
     } else { // fixed joint
         const s6 Iac = symmul(IA, B.cJ);
         Ic = IA;
@@ -659,6 +703,7 @@ __device__ __forceinline__ void wv_joint_inward(const DynModel &M, const WaveTab
 }
 
 // acceleration of body b from its parent's (ap); leaves its own in ap
+template <int FS>
 __device__ __forceinline__ void wv_joint_outward(const DynModel &M, const WaveTables &W, int b, WvBody &B, s6 &ap, const float *fac) {
     const int jt = W.c[b].jtype;
     s6 ai = ap + B.cJ;
@@ -668,8 +713,8 @@ __device__ __forceinline__ void wv_joint_outward(const DynModel &M, const WaveTa
         for (int q = 0; q < 3; ++q) {
             float ka = 0.f;
             PARC_UNROLL
-            for (int a = 0; a < 6; ++a) ka += fac[(6 * q + a) * 64] * ai.a[a];
-            q3[q] = fac[(18 + q) * 64] - ka;
+            for (int a = 0; a < 6; ++a) ka += fac[(6 * q + a) * FS] * ai.a[a];
+            q3[q] = fac[(18 + q) * FS] - ka;
         }
         B.qdd = mk(q3[0], q3[1], q3[2]);
         const v3 wj = mulv(qmat(B.bq), B.qdd);
@@ -677,8 +722,8 @@ __device__ __forceinline__ void wv_joint_outward(const DynModel &M, const WaveTa
     } else if (jt == DJ_HINGE) {
         float ka = 0.f;
         PARC_UNROLL
-        for (int a = 0; a < 6; ++a) ka += fac[a * 64] * ai.a[a];
-        const float qa = fac[6 * 64] - ka;
+        for (int a = 0; a < 6; ++a) ka += fac[a * FS] * ai.a[a];
+        const float qa = fac[6 * FS] - ka;
         B.qdd = mk(qa, 0.f, 0.f);
         const v3 wj = qa * mulv(qmat(B.bq), mk(W.c[b].axis[0], W.c[b].axis[1], W.c[b].axis[2]));
         ai = ai + s6mk(wj, cross(B.r, wj));
@@ -721,7 +766,7 @@ __device__ __forceinline__ void wv_store_joint(const DynModel &M, const WaveTabl
 __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__restrict__ Mp, const WaveTables *__restrict__ Wp, DynTerrain T,
                                                           ParcEnvBuffers buf, const float *__restrict__ action,
                                                           const float *__restrict__ env_off_all, float *__restrict__ root_shadow,
-                                                          float4 *__restrict__ prep, int N, int epb) {
+                                                          float4 *__restrict__ prep, float *__restrict__ man_g, int N, int epb) {
     extern __shared__ float smem[];
     const DynModel &M = *Mp;
     const WaveTables &W = *Wp;
@@ -741,7 +786,7 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
 
     float *s_attkin = smem + WV_OFF_ATTKIN + lane, *s_up = smem + WV_OFF_UP + lane, *s_attacc = smem + WV_OFF_ATTACC + lane;
     float *s_rootp = smem + WV_OFF_ROOTP + lane, *s_patch = smem + WV_OFF_PATCH + lane, *s_pmax = smem + WV_OFF_PMAX + lane;
-    float *s_fac = smem + WV_OFF_FAC + lane, *s_rooti = smem + WV_OFF_ROOTI + lane, *s_pmax3 = smem + WV_OFF_PMAX3 + lane;
+    float *s_rooti = smem + WV_OFF_ROOTI + lane, *s_pmax3 = smem + WV_OFF_PMAX3 + lane;
     // hand-off flags: workgroup-scope atomics in LDS (release store by the producer after its record, acquire load by the consumer before
     // it reads the record); [15] = "a wait of this block timed out"
     int *s_flag = reinterpret_cast<int *>(smem + WV_OFF_FLAG);
@@ -750,6 +795,22 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
 
     const float *dp = buf.char_dof_pos + (size_t)D_ * ec, *dv = buf.char_dof_vel + (size_t)D_ * ec, *ac = action + (size_t)D_ * ec;
     WvBody limb[WV_MAXLEN], trunk[WV_MAXLEN];
+    // joint-space factors K = U D^-1, D^-1 u between the inward and the outward pass: the limb's in registers; wave 0's trunk factors
+    // (positions 1.., the root has none) in LDS -- with them in registers too the kernel spills (512 registers + 76 B of scratch per lane)
+    float fac_l[WV_MAXLEN][WV_FAC];
+#ifdef PARC_TRUNK_FAC_REGS
+    float fac_t[WV_MAXLEN][WV_FAC];
+#define WV_TFS 1
+#define WV_TFAC(k) fac_t[k]
+#else
+    float *s_tfac = smem + WV_OFF_TFAC + lane;
+#define WV_TFS 64
+#define WV_TFAC(k) (s_tfac + ((k) - 1) * WV_FAC * 64)
+#endif
+    WvMan man;                                                // this wave's per-lane list of contact planes
+    man.lds = smem + WV_OFF_MAN + W.man_base[w] * (8 * 64) + lane; man.cap = W.man_cap[w];
+    man.glb = man_g + ((size_t)blockIdx.x * WV_MAXLIMB + w) * (WV_MAN_OVF * 8 * 64) + lane;
+    man.cur = 0; man.cnt = 0ull;
     PARC_UNROLL
     for (int k = 0; k < WV_MAXLEN; ++k) {
         if (k < llen) wv_load_joint(M, W, W.body[lc][k], limb[k], dp, dv, ac);
@@ -763,6 +824,7 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
 
     WvCtx X;
     X.s_patch = s_patch; X.s_pmax = s_pmax; X.s_pmax3 = s_pmax3; X.dt = dt;
+
     const float eo0 = env_off_all[3 * ec], eo1 = env_off_all[3 * ec + 1], eo2 = env_off_all[3 * ec + 2];
     X.cell_min = fminf(T.dx, T.dy);
     X.pox = cell_of(rp_buf.x + eo0, T.min_x, T.dx) - DYN_PATCH / 2; X.poy = cell_of(rp_buf.y + eo1, T.min_y, T.dy) - DYN_PATCH / 2;
@@ -896,6 +958,8 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
         WSTAMP(2);
         WTL(0); // substep start: parent kinematics received (limbs) / own trunk kinematics done (wave 0)
         const v3 rootp = mk(s_rootp[0], s_rootp[64], s_rootp[128]);
+        const bool discover = sub % M.man_period == 0; // contact discovery in this substep (uniform); the others re-evaluate the cached planes
+        man.cur = 0;
         // ---- inward pass of this wave's limb -----------------------------------------------------------------------------
         sym6 Icl; s6 pcl = s6zero();   // carry of this wave's limb
         PARC_UNROLL
@@ -906,8 +970,8 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
             const m3 R = qmat(limb[k].bq);
             sym6 IA = Icl; s6 pA = pcl;
             WSTAMP(15);
-            wv_body_inertia(M, W, T, X, b, limb[k], R, rootp, IA, pA WSTAMP_ARGS);
-            wv_joint_inward(M, W, b, limb[k], R, dt, IA, pA, Icl, pcl, s_fac + W.fac_off[lc][k] * 64);
+            wv_body_inertia(M, W, T, X, b, limb[k], R, rootp, IA, pA, man, 3 + k, discover WSTAMP_ARGS);
+            wv_joint_inward<1>(M, W, b, limb[k], R, dt, IA, pA, Icl, pcl, fac_l[k]);
             WPIN(Icl, pcl);
             WSTAMP(14);
         };
@@ -925,7 +989,7 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
             PARC_UNROLL
             for (int i = 0; i < 21; ++i) IA.s[i] = 0.f;
             WSTAMP(15);
-            wv_body_inertia(M, W, T, X, W.body[0][k], rb, qmat(rb.bq), rootp, IA, pA WSTAMP_ARGS);
+            wv_body_inertia(M, W, T, X, W.body[0][k], rb, qmat(rb.bq), rootp, IA, pA, man, k, discover WSTAMP_ARGS);
             float *sr = s_rooti + k * 30 * 64;
             PARC_UNROLL
             for (int i = 0; i < 21; ++i) sr[i * 64] = IA.s[i];
@@ -961,6 +1025,13 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
         }
         if (W.rec_wave[0] == w) prep_record(0); // the root body's record: needed last, so after this wave's own limb
         WSTAMP(3);
+#ifdef PARC_COUNTS
+        if (sub % M.man_period == 0) { // planes this wave holds after a discovery: histogram of the largest per-lane count
+            int mb = man.cur;
+            for (int o = 32; o > 0; o >>= 1) mb = max(mb, __shfl_xor(mb, o));
+            if (lane == 0) atomicAdd(&g_wave_hist[15][w][min(mb, 15)], 1ull);
+        }
+#endif
         // ---- wave 0: trunk inward pass, floating-base solve, trunk outward pass, integration -----------------------------
         if (w == 0) {
             sym6 Ict; s6 pct = s6zero();   // carry of the trunk
@@ -983,7 +1054,7 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
                     trunk[k].fcon = mk(sr[27 * 64], sr[28 * 64], sr[29 * 64]);
                 } else {
                     WSTAMP(15);
-                    wv_body_inertia(M, W, T, X, b, trunk[k], R, rootp, IA, pA WSTAMP_ARGS);
+                    wv_body_inertia(M, W, T, X, b, trunk[k], R, rootp, IA, pA, man, 6 + k, discover WSTAMP_ARGS);
                 }
                 for (int ci = 0; ci < W.nchild[k]; ++ci) {
                     const int c = W.child[k][ci];
@@ -1032,7 +1103,7 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
                     PARC_UNROLL
                     for (int a = 0; a < 6; ++a) acc_root.a[a] = xs[a];
                 } else {
-                    wv_joint_inward(M, W, b, trunk[k], R, dt, IA, pA, Ict, pct, s_fac + W.fac_off[0][k] * 64);
+                    wv_joint_inward<WV_TFS>(M, W, b, trunk[k], R, dt, IA, pA, Ict, pct, WV_TFAC(k));
                 }
             };
             PARC_UNROLL
@@ -1043,7 +1114,7 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
             for (int k = 0; k < WV_MAXLEN; ++k) {
                 if (k < tlen) {
                     const int b = W.body[0][k];
-                    if (b != 0) wv_joint_outward(M, W, b, trunk[k], ap, s_fac + W.fac_off[0][k] * 64);
+                    if (b != 0) wv_joint_outward<WV_TFS>(M, W, b, trunk[k], ap, WV_TFAC(k));
                     const int slot = W.att_slot[k];
                     if (slot >= 0) { // the limbs hanging here can start their outward pass
                         PARC_UNROLL
@@ -1092,7 +1163,7 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
             for (int k = 0; k < WV_MAXLEN; ++k) {
                 if (k < llen) {
                     const int b = W.body[lc][k];
-                    wv_joint_outward(M, W, b, limb[k], ap, s_fac + W.fac_off[lc][k] * 64);
+                    wv_joint_outward<1>(M, W, b, limb[k], ap, fac_l[k]);
                     wv_integrate_joint(M, W, b, limb[k], dt);
                 }
             }

@@ -1576,6 +1576,11 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 
 #define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return fail(PARC_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(_e)); } while (0)
 
+// k_dynamics_wave, envs per block.  A block's latency does not depend on how many of its 64 lanes carry an env, so when 64-env blocks
+// would leave half the CUs without one (a multi-GPU shard), 32-env blocks put the same work on twice the CUs: -5 % at 8 192 envs (less LDS
+// and memory traffic per block; the vector instructions themselves take as long with 32 lanes as with 64)
+static int wave_envs_per_block(int N, int num_cus) { return (N + 63) / 64 <= num_cus / 2 ? 32 : 64; }
+
 struct ParcEnv {
     ParcEnvConfig cfg;
     int B, J, D, K, S, R, N, M = 0, T = 1;
@@ -1585,6 +1590,7 @@ struct ParcEnv {
     bool done_list_fresh = false;     // a step has produced a done list that parc_env_reset_done has not consumed yet
     StepParams sp;
     float4 *d_prep = nullptr;
+    float *d_man_ovf = nullptr;       // k_dynamics_wave: overflow area of the per-lane contact-plane lists, [blocks][4 waves][WV_MAN_OVF][8][64]
     float *d_root_shadow = nullptr;   // [N][6]: root position the dynamics last wrote + what that write rounded away (k_dynamics_wave)
     parcdyn::DynModel h_dyn;
     parcdyn::DynModel *d_dyn = nullptr;
@@ -1630,7 +1636,7 @@ extern "C" const char *parc_last_error(void) { return g_err.c_str(); }
 extern "C" int parc_abi_version(void) { return PARC_ABI_VERSION; }
 
 static void free_dev(ParcEnv *e) {
-    void *ptrs[] = {e->d_root_shadow, e->d_prep, e->d_dyn, e->d_coop, e->d_wave, e->d_tab, e->d_ray, e->d_env_off, e->d_hf, e->d_motion_off, e->d_records, e->d_meta, e->d_weights, e->d_fail,
+    void *ptrs[] = {e->d_man_ovf, e->d_root_shadow, e->d_prep, e->d_dyn, e->d_coop, e->d_wave, e->d_tab, e->d_ray, e->d_env_off, e->d_hf, e->d_motion_off, e->d_records, e->d_meta, e->d_weights, e->d_fail,
                     e->d_cdf, e->d_ema, e->d_done_list, e->d_done_key, e->d_chunk_count, e->d_motion_done, e->d_reset_count, e->d_reset_calls,
                     e->d_scratch_jr};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -1744,6 +1750,12 @@ extern "C" int parc_env_create(const ParcEnvConfig *cfg, ParcEnv **out) {
         free_dev(e); delete e;
         return fail(PARC_ERR_HIP, std::string("device allocation failed: ") + hipGetErrorString(r));
     }
+    {
+        hipDeviceProp_t prop;
+        (void)hipGetDeviceProperties(&prop, cfg->device);
+        e->grid_waves = prop.multiProcessorCount * 16; // persistent waves; each strides over envs
+        e->num_cus = prop.multiProcessorCount;
+    }
     if (cfg->enable_dynamics) {
         memset(&e->h_dyn, 0, sizeof(e->h_dyn));
         parcdyn::fill_dyn_model(e->h_dyn, cfg->model, cfg->dynamics, cfg->action_low, cfg->action_high);
@@ -1780,8 +1792,12 @@ extern "C" int parc_env_create(const ParcEnvConfig *cfg, ParcEnv **out) {
                 r = hipMalloc((void **)&e->d_root_shadow, sizeof(float) * 6 * N);
                 if (r == hipSuccess) r = hipMemset(e->d_root_shadow, 0xff, sizeof(float) * 6 * N); // NaN: matches no buffer value
             }
+            if (r == hipSuccess) { // overflow area of the contact-plane lists (never read before it is written)
+                const int epb = wave_envs_per_block(N, e->num_cus);
+                r = hipMalloc((void **)&e->d_man_ovf, sizeof(float) * (size_t)((N + epb - 1) / epb) * WV_MAXLIMB * WV_MAN_OVF * 8 * 64);
+            }
             if (r == hipSuccess)
-                r = hipFuncSetAttribute((const void *)parcdyn::k_dynamics_wave, hipFuncAttributeMaxDynamicSharedMemorySize, parcdyn::wv_lds_floats(e->h_wave.fac_total) * (int)sizeof(float));
+                r = hipFuncSetAttribute((const void *)parcdyn::k_dynamics_wave, hipFuncAttributeMaxDynamicSharedMemorySize, parcdyn::wv_lds_floats() * (int)sizeof(float));
         } else if (e->use_coop) {
             r = up((void **)&e->d_coop, &e->h_coop, sizeof(e->h_coop));
         }
@@ -1801,10 +1817,6 @@ extern "C" int parc_env_create(const ParcEnvConfig *cfg, ParcEnv **out) {
     e->nchunks = (e->N + 1023) / 1024;
     if (e->nchunks > 1024) { free_dev(e); delete e; return fail(PARC_ERR_INVALID, "num_envs must be <= 1048576 per handle"); }
 
-    hipDeviceProp_t prop;
-    (void)hipGetDeviceProperties(&prop, cfg->device);
-    e->grid_waves = prop.multiProcessorCount * 16; // persistent waves; each strides over envs
-    e->num_cus = prop.multiProcessorCount;
     *out = e;
     return PARC_OK;
 }
@@ -1955,13 +1967,10 @@ static int launch_dynamics(ParcEnv *e, const float *action_dev, hipStream_t st) 
     parcdyn::DynTerrain T;
     T.hf = e->d_hf; T.X = e->sp.X; T.Y = e->sp.Y; T.min_x = e->sp.min_x; T.min_y = e->sp.min_y; T.dx = e->sp.dx; T.dy = e->sp.dy;
     if (e->use_wave) {
-        // A block's latency does not depend on how many of its 64 lanes carry an env, so when 64-env blocks would leave half the CUs
-        // without one (a multi-GPU shard), 32-env blocks put the same work on twice the CUs: -5 % at 8 192 envs (less LDS and memory
-        // traffic per block; the vector instructions themselves take as long with 32 lanes as with 64)
-        const int epb = (e->N + 63) / 64 <= e->num_cus / 2 ? 32 : 64;
-        hipLaunchKernelGGL(parcdyn::k_dynamics_wave, dim3((e->N + epb - 1) / epb), dim3(256), parcdyn::wv_lds_floats(e->h_wave.fac_total) * sizeof(float), st,
+        const int epb = wave_envs_per_block(e->N, e->num_cus);
+        hipLaunchKernelGGL(parcdyn::k_dynamics_wave, dim3((e->N + epb - 1) / epb), dim3(256), parcdyn::wv_lds_floats() * sizeof(float), st,
                            (const parcdyn::DynModel *)e->d_dyn, (const parcdyn::WaveTables *)e->d_wave, T, e->sp.buf, action_dev,
-                           (const float *)e->d_env_off, e->d_root_shadow, e->d_prep, e->N, epb);
+                           (const float *)e->d_env_off, e->d_root_shadow, e->d_prep, e->d_man_ovf, e->N, epb);
     }
     else if (e->use_coop)
         hipLaunchKernelGGL(parcdyn::k_dynamics_coop, dim3((e->N + CO_ENVS - 1) / CO_ENVS), dim3(64), 0, st, (const parcdyn::DynModel *)e->d_dyn,
@@ -2485,6 +2494,17 @@ extern "C" int parc_env_dynamics_timeouts(ParcEnv *e) {
     return (int)(v > 0x7fffffffu ? 0x7fffffffu : v);
 }
 
+// Contact planes k_dynamics_wave had no room for (the per-lane list's LDS share + overflow area were full; parc_dynamics_wave.hpp,
+// WvMan): must stay 0 -- a dropped plane is a contact the substeps after a discovery do not see.
+extern "C" int parc_env_dynamics_manifold_drops(ParcEnv *e) {
+    if (!e) return fail(PARC_ERR_INVALID, "null env");
+    unsigned int v = 0;
+    HIPCHK(hipSetDevice(e->cfg.device));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(&v, HIP_SYMBOL(parcdyn::g_wave_man_drops), sizeof(v)));
+    return (int)(v > 0x7fffffffu ? 0x7fffffffu : v);
+}
+
 extern "C" float parc_env_last_dynamics_ms(ParcEnv *e) { return e ? e->last_dyn_ms : 0.f; }
 
 extern "C" const char *parc_env_dynamics_kernel(ParcEnv *e) {
@@ -2536,6 +2556,18 @@ extern "C" int parc_env_debug_wave_counts(double *out128) {
     HIPCHK(hipMemcpyFromSymbol(h, HIP_SYMBOL(parcdyn::g_wave_cnt), sizeof(h)));
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(parcdyn::g_wave_cnt), z, sizeof(z)));
     for (int i = 0; i < 128; ++i) out128[i] = (double)h[i];
+    return PARC_OK;
+}
+#endif
+
+#ifdef PARC_STAMPS
+// Diagnostic: manifold-size histograms of k_dynamics_wave [16][4][16] (see g_wave_hist; -DPARC_COUNTS builds fill them), cleared by the call.
+extern "C" int parc_env_debug_wave_hist(double *out1024) {
+    static unsigned long long h[1024], z[1024];
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(h, HIP_SYMBOL(parcdyn::g_wave_hist), sizeof(h)));
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(parcdyn::g_wave_hist), z, sizeof(z)));
+    for (int i = 0; i < 1024; ++i) out1024[i] = (double)h[i];
     return PARC_OK;
 }
 #endif
