@@ -38,8 +38,6 @@ namespace parcdyn {
 #define WV_MAXLEN 3   // bodies per chain
 #define WV_MAXLIMB 4  // limb chains = waves per block
 #define WV_MAXATT 3   // trunk bodies that carry limbs
-#define WV_PI (DYN_PATCH - 4)
-#define WV_P3 (DYN_PATCH - 2)  // cells that have a full 3x3 neighbourhood inside the patch
 #define WV_FAC 21     // K (18) + D^-1 u (3); a hinge uses slots 0..5 (K) and 6 (D^-1 u)
 
 // Everything the wave kernel reads about a body, contiguous (256 B): the body index is wave-uniform but dynamic, so every
@@ -68,6 +66,8 @@ struct WaveTables {
     int body[1 + WV_MAXLIMB][WV_MAXLEN];
     int par_slot[1 + WV_MAXLIMB];          // attach slot of the trunk body a limb hangs off
     int early[1 + WV_MAXLIMB];             // limb hangs off a non-root trunk body: finished before the trunk's upper part starts
+    int ep_trunk_wave, ep_head_wave;       // epilogue: which waves (>= 1) form the prep-record quaternions of the trunk joints / the heading terms of
+                                           // the root from what wave 0 hands over (-1: wave 0 does it itself)
     int helper;                            // wave (>= 1) of an early limb: idle in part B, it prepares own inertia + contacts of trunk bodies; -1 if none
     int prep[WV_MAXLEN];                   // per trunk position: 1 = own inertia + contacts prepared by another wave (rec_wave), handed over as a record
     int rec_wave[WV_MAXLEN];               // that wave (>= 1), or -1: wave 0 does the body itself.  Position 0 (the root body) is prepared AFTER the
@@ -89,8 +89,7 @@ struct WaveTables {
 #define WV_OFF_ATTACC (WV_OFF_UP + WV_MAXLIMB * 27 * 64)
 #define WV_OFF_ROOTP (WV_OFF_ATTACC + WV_MAXATT * 6 * 64)
 #define WV_OFF_PATCH (WV_OFF_ROOTP + 3 * 64)
-#define WV_OFF_PMAX (WV_OFF_PATCH + DYN_PATCH * DYN_PATCH * 64)
-#define WV_OFF_ROOTI (WV_OFF_PMAX + WV_PI * WV_PI * 64)
+#define WV_OFF_ROOTI (WV_OFF_PATCH + DYN_PATCH * DYN_PATCH * 64)
 #define WV_OFF_FLAG (WV_OFF_ROOTI + WV_MAXLEN * 30 * 64)   // hand-off flags between the waves of a block (see WV_F_*)
 // A flag holds the number of substeps for which its producer has published: a consumer of substep `sub` waits for > sub.
 #define WV_F_KIN(slot) (12 + (slot)) // wave 0: kinematics of attach slot (0..2) (+ the root position, with the root body's slot)
@@ -98,20 +97,17 @@ struct WaveTables {
 #define WV_F_REC(k) (5 + (k)) // record (own inertia + contacts) of trunk position k (0..2), prepared by wave rec_wave[k]
 #define WV_F_HAND 11           // epilogue: wave 0 has handed the trunk joints' dofs to the helper wave
 #define WV_F_ACC(slot) (8 + (slot)) // wave 0: spatial acceleration of attach slot (0..2)
-// The contact planes of the four waves (WvMan: man_total slots of 8 x 64 floats) take the rest of the CU's LDS.  The 3x3 running maximum of
-// the height patch (the prologue's intermediate for the 5x5 table) is dead after the prologue and aliases the head of that region.  (Round
-// 3 kept the joint-space factors K = U D^-1, D^-1 u in LDS here, 50 KB: they are register arrays now -- a lane reads back what it wrote --
-// which is what makes the room.)
+// The contact planes of the four waves (WvMan: man_total slots of 8 x 64 floats) take the rest of the CU's LDS.  (Round 3 kept the
+// joint-space factors K = U D^-1, D^-1 u of all bodies here, 50 KB, and the running maxima of the height patch, 19 KB: the limbs' factors
+// are register arrays now -- a lane reads back what it wrote --, the maxima are gone, which is what makes the room.)
 #ifdef PARC_TRUNK_FAC_REGS
 #define WV_OFF_MAN (WV_OFF_FLAG + 64)
 #else
 #define WV_OFF_TFAC (WV_OFF_FLAG + 64)                        // wave 0: joint-space factors of trunk positions 1..2
 #define WV_OFF_MAN (WV_OFF_TFAC + (WV_MAXLEN - 1) * WV_FAC * 64)
 #endif
-#define WV_OFF_PMAX3 WV_OFF_MAN
 #define WV_LDS_BYTES (160 * 1024)
 #define WV_MAN_TOTAL ((WV_LDS_BYTES / 4 - WV_OFF_MAN) / (8 * 64))
-static_assert(WV_MAN_TOTAL * 8 * 64 >= WV_P3 * WV_P3 * 64, "the 3x3 table fits the region it aliases");
 inline int wv_lds_floats() { return WV_OFF_MAN + WV_MAN_TOTAL * 8 * 64; }
 
 inline bool build_wave_tables(const DynModel &M, const CoopTables &C, WaveTables &W) {
@@ -166,6 +162,10 @@ inline bool build_wave_tables(const DynModel &M, const CoopTables &C, WaveTables
     for (int k = 1; k < W.len[0]; ++k)
         if (W.rec_wave[k] < 0 && W.att_slot[k] < 0 && root_limb >= 1 && natt < WV_MAXATT) { W.att_slot[k] = natt++; W.rec_wave[k] = root_limb; }
     for (int k = 0; k < W.len[0]; ++k) W.prep[k] = W.rec_wave[k] >= 1 ? 1 : 0;
+    // epilogue shares: wave 0 is the last one out of the substep loop, so the transcendental-heavy prep-record work on ITS state (heading
+    // terms of the root, dof -> quat of the trunk joints) goes to two other waves, which are through their own stores by then
+    W.ep_head_wave = W.helper;
+    W.ep_trunk_wave = W.helper >= 1 && root_limb >= 1 ? root_limb : W.helper;
     {   // LDS shares of the plane lists: two slots each, the rest in proportion to the candidates a wave discovers
         int cand[WV_MAXLIMB] = {0, 0, 0, 0}, tot = 0, used = 0;
         for (int w = 0; w < WV_MAXLIMB; ++w) {
@@ -284,7 +284,7 @@ __device__ __forceinline__ void wv_fk_body(const DynModel &M, const WaveTables &
 
 
 struct WvCtx { // per-lane constants of the control step
-    const float *s_patch, *s_pmax, *s_pmax3; // + lane
+    const float *s_patch;     // + lane
     int pox, poy;             // global cell index of patch cell (0,0)
     float cell_min, dt;
     DynTerrain Tp;            // the PATCH FRAME: origin = centre of patch cell (DYN_PATCH/2, DYN_PATCH/2), so cell_of(., Tp) is a patch index.
@@ -298,7 +298,7 @@ struct WvCtx { // per-lane constants of the control step
 // g_wave_man_drops (parc_env_dynamics_manifold_drops: must stay 0, the GPU tests check it).  The list is filled body by body in the order
 // the wave visits its bodies (`site` = the static index of the visit: records 0..2, limb bodies 3..5, wave 0's own trunk bodies 6..8) and
 // walked in the same order in every substep: `cur` is the running start of the current body, `cnt` holds the per-site counts (6 bits each).
-#define WV_MAN_OVF 12
+#define WV_MAN_OVF 20
 struct WvMan { float *lds, *glb; int cap, cur; unsigned long long cnt; };
 __device__ unsigned int g_wave_man_drops;
 
@@ -375,19 +375,19 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
     // evaluation loop's trip count is the LARGEST per-lane plane count of the body in the wave (feet: 4-8 of 10 candidates x 4 columns).
     const int site6 = 6 * site;
     if (discover) {
-        // A body whose bounding sphere (+ the largest margin) clears every column its collision spheres could touch is skipped (exact:
-        // nothing is emitted).  The sphere centres lie within brho of the bounding centre, i.e. (brho < one cell) in the 3x3 cells around
-        // its cell, and each touches at most the columns one cell further: the 5x5 window.
+        // Is the straight path applicable to this lane?  The sphere centres lie within brho of the bounding centre, i.e. (brho < one cell)
+        // in the 3x3 cells around its cell, and each reaches at most the columns one cell further: with the bounding centre's cell at
+        // least two cells inside the staged patch every height the narrow phase asks for is in LDS.  (Rounds 1-3 also kept a 5x5 running
+        // maximum of the patch to cull bodies and points that clear every column of that window: with lane = env the cull never skipped
+        // an instruction -- some lane of the wave always needs the candidate -- and its two table passes cost two block barriers in the
+        // prologue; the narrow phase's own tests reject the same candidates.)
         const float brho = W.c[b].brho;
         const float smax = M.spec_max;
-        float hmax = 3.0e38f; // highest column any sphere of this body can touch (+inf when the 5x5 window is not applicable)
+        bool inwin;
         {
             const v3 cb = r + mulv(R, mk(W.c[b].bc[0], W.c[b].bc[1], W.c[b].bc[2]));
             const int bx = cell_of(cb.x + rootp.x, Tp.min_x, Tp.dx), by = cell_of(cb.y + rootp.y, Tp.min_y, Tp.dy);
-            if (brho < X.cell_min && bx >= 2 && bx < DYN_PATCH - 2 && by >= 2 && by < DYN_PATCH - 2) {
-                hmax = X.s_pmax[((bx - 2) * WV_PI + by - 2) * 64];
-                if (cb.z + rootp.z - brho - smax > hmax) hmax = -3.0e38f; // clears everything: no point survives the test below
-            }
+            inwin = brho < X.cell_min && bx >= 2 && bx < DYN_PATCH - 2 && by >= 2 && by < DYN_PATCH - 2;
         }
         // Narrow phase.  A sphere can only come within the margin of the column of its own cell and of the neighbours on the sides whose
         // face is closer than radius + margin (for rad + spec_max < half a cell: at most the x-side, the y-side and their diagonal; the far
@@ -443,7 +443,7 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
             const float fast_r = X.cell_min * 0.5f - 2e-3f - smax;
             bool wide = false;
             for (int pi = 0; pi < npt; ++pi) wide = wide || !(W.colp[pt0 + pi][3] < fast_r); // uniform
-            slow = (hmax > 1.0e38f) || (wide && hmax > -1.0e38f);
+            slow = !inwin || wide;
         }
         // narrow phase of one candidate sphere (body-frame centre pb, x relative to O, g = x + rootp in the patch frame) of a lane whose
         // spheres all lie in the inner patch: own column, then the neighbour columns on the sides whose face is closer than radius + margin
@@ -493,7 +493,7 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
                 const v3 pb = mk(cur.x, cur.y, cur.z);
                 const v3 x = r + mulv(R, pb);
                 const v3 g = x + rootp;
-                const bool mine = !slow && !(g.z - cur.r - smax > hmax); // the sphere reaches down to the highest column of the body's window
+                const bool mine = !slow;
 #ifdef PARC_COUNTS
                 cnt_pairs += __popcll(__ballot(mine)); cnt_exec += __any(mine) ? 1 : 0;
 #endif
@@ -507,11 +507,11 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
         WSTAMP(13); // narrow phase of the collision points
         // The body's segments: where a shaft / sole edge crosses a grid line with a step, the closest point to that edge is one more candidate
         // sphere (segment_edge_point, parc_dynamics.hpp), kept in the body frame like a point's centre.
-        if (__any(hmax > -1.0e38f)) {
+        {
             for (int si = 0; si < nsg; ++si) {
                 v3 Q = rootp;
                 const float wq = seg_point(sg0 + si, Q);
-                const bool has = wq > 0.f && !slow && !(Q.z - W.seg[sg0 + si][3] - smax > hmax);
+                const bool has = wq > 0.f && !slow;
 #ifdef PARC_COUNTS
                 cnt_pairs += __popcll(__ballot(has)); cnt_exec += __any(has) ? 1 : 0;
 #endif
@@ -535,7 +535,6 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
                     pb = mulTv(R, x - r);
                 }
                 const v3 g = x + rootp;
-                if (g.z - rad - smax > hmax) continue;
                 const v3 vpt = s6lin(B.vel) + cross(s6ang(B.vel), x);
                 sphere_discover(M, Tp, g, rad, vpt, top_slow, [&](float pen, v3 n) { push(pb, n, pen + dot(n, g), wq); });
             }
@@ -543,7 +542,7 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
         man.cnt = (man.cnt & ~(63ull << site6)) | ((unsigned long long)n_new << site6);
 #ifdef PARC_COUNTS
         {
-            const unsigned long long m_near = __ballot(hmax > -1.0e38f), m_slow = __ballot(slow);
+            const unsigned long long m_near = __ballot(inwin), m_slow = __ballot(slow);
             if ((threadIdx.x & 63) == 0) {
                 atomicAdd(&g_wave_cnt[b][0], 64ull); atomicAdd(&g_wave_cnt[b][1], (unsigned long long)__popcll(m_near));
                 atomicAdd(&g_wave_cnt[b][2], m_near ? 1ull : 0ull); atomicAdd(&g_wave_cnt[b][3], (unsigned long long)cnt_pairs);
@@ -560,32 +559,33 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
     v3 fsum = mk(0.f, 0.f, 0.f);
     {
         const int n_me = (int)((man.cnt >> site6) & 63ull);
-        for (int t = 0; __any(t < n_me); ++t) {
-            const bool act = t < n_me;
-            const int slot = act ? man.cur + t : 0;
+        // plane t of the lane (valid address for every lane: slot 0 when it has no plane t)
+        auto fetch = [&](int t, float (&e_)[8]) __attribute__((always_inline)) {
+            const int slot = t < n_me ? man.cur + t : 0;
             const bool inl = slot < man.cap;
-            float e_[8];
-            {
-                const float *q_ = man.lds + (inl ? slot : 0) * (8 * 64);
-                PARC_UNROLL
-                for (int f = 0; f < 8; ++f) e_[f] = q_[f * 64];
-            }
+            const float *q_ = man.lds + (inl ? slot : 0) * (8 * 64);
+            PARC_UNROLL
+            for (int f = 0; f < 8; ++f) e_[f] = q_[f * 64];
             if (__any(!inl)) { // overflow area (rare): the lane's own earlier stores, global memory
                 if (!inl) {
-                    const float *q_ = man.glb + (slot - man.cap) * (8 * 64);
+                    const float *g_ = man.glb + (slot - man.cap) * (8 * 64);
                     PARC_UNROLL
-                    for (int f = 0; f < 8; ++f) e_[f] = __builtin_nontemporal_load(q_ + f * 64);
+                    for (int f = 0; f < 8; ++f) e_[f] = __builtin_nontemporal_load(g_ + f * 64);
                 }
             }
+        };
+        for (int t = 0; __any(t < n_me); ++t) {
+            float e_[8];
+            fetch(t, e_);
             const v3 x = r + mulv(R, mk(e_[0], e_[1], e_[2]));
             const v3 n = mk(e_[3], e_[4], e_[5]);
             const float pen = e_[6] - dot(n, x + rootp);
-            const bool hit = act && pen > 0.f;
+            const bool hit = t < n_me && pen > 0.f;
             if (__any(hit)) {
-                if (hit) {
-                    const v3 vpt = s6lin(B.vel) + cross(s6ang(B.vel), x);
-                    contact_apply(M, dt, x, vpt, pen, n, IA, pA, fsum, e_[7]);
-                }
+                const v3 vpt = s6lin(B.vel) + cross(s6ang(B.vel), x);
+                // (tried in round 4, both slower by 3 %: a short form for normals that are exactly +z behind an __all test -- two code paths
+                // instead of one --, and fetching plane t + 1 while plane t is evaluated -- eight more live registers and their copies)
+                if (hit) contact_apply(M, dt, x, vpt, pen, n, IA, pA, fsum, e_[7]);
             }
         }
         man.cur += n_me;
@@ -785,8 +785,8 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
     const int llen = has_limb ? W.len[lc] : 0, tlen = w == 0 ? W.len[0] : 0;
 
     float *s_attkin = smem + WV_OFF_ATTKIN + lane, *s_up = smem + WV_OFF_UP + lane, *s_attacc = smem + WV_OFF_ATTACC + lane;
-    float *s_rootp = smem + WV_OFF_ROOTP + lane, *s_patch = smem + WV_OFF_PATCH + lane, *s_pmax = smem + WV_OFF_PMAX + lane;
-    float *s_rooti = smem + WV_OFF_ROOTI + lane, *s_pmax3 = smem + WV_OFF_PMAX3 + lane;
+    float *s_rootp = smem + WV_OFF_ROOTP + lane, *s_patch = smem + WV_OFF_PATCH + lane;
+    float *s_rooti = smem + WV_OFF_ROOTI + lane;
     // hand-off flags: workgroup-scope atomics in LDS (release store by the producer after its record, acquire load by the consumer before
     // it reads the record); [15] = "a wait of this block timed out"
     int *s_flag = reinterpret_cast<int *>(smem + WV_OFF_FLAG);
@@ -823,7 +823,7 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
     v3 rw = mk(buf.char_root_ang_vel[3 * ec], buf.char_root_ang_vel[3 * ec + 1], buf.char_root_ang_vel[3 * ec + 2]);
 
     WvCtx X;
-    X.s_patch = s_patch; X.s_pmax = s_pmax; X.s_pmax3 = s_pmax3; X.dt = dt;
+    X.s_patch = s_patch; X.dt = dt;
 
     const float eo0 = env_off_all[3 * ec], eo1 = env_off_all[3 * ec + 1], eo2 = env_off_all[3 * ec + 2];
     X.cell_min = fminf(T.dx, T.dy);
@@ -845,7 +845,7 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
         if (sh[0] == rp_buf.x && sh[1] == rp_buf.y && sh[2] == rp_buf.z) rlo = mk(sh[3], sh[4], sh[5]);
     }
     v3 rp = mk((rp_buf.x - anc.x) + rlo.x, (rp_buf.y - anc.y) + rlo.y, (rp_buf.z - anc.z) + rlo.z);
-    // local height patch of each env (the 4 waves share the 81 cells), then its 3x3 and 5x5 running maxima.  The loops are
+    // local height patch of each env (the 4 waves share the 81 cells).  The loops are
     // fully unrolled with a uniform predicate so that all loads of a pass are in flight together (one resident wave per
     // SIMD: a load per iteration would expose its whole latency 20 times).
     {
@@ -863,41 +863,8 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
         }
     }
     __syncthreads();
-    {
-        constexpr int N3 = (WV_P3 * WV_P3 + 3) / 4;
-        float mv[N3];
-        PARC_UNROLL
-        for (int it = 0; it < N3; ++it) {
-            const int i = w + 4 * it < WV_P3 * WV_P3 ? w + 4 * it : 0;
-            const int pi_ = i / WV_P3 + 1, pj_ = i % WV_P3 + 1;
-            float m = -3.0e38f;
-            PARC_UNROLL
-            for (int a = -1; a <= 1; ++a) {
-                PARC_UNROLL
-                for (int q = -1; q <= 1; ++q) m = fmaxf(m, s_patch[((pi_ + a) * DYN_PATCH + pj_ + q) * 64]);
-            }
-            mv[it] = m;
-        }
-        PARC_UNROLL
-        for (int it = 0; it < N3; ++it) if (w + 4 * it < WV_P3 * WV_P3) s_pmax3[(w + 4 * it) * 64] = mv[it];
-    }
-    __syncthreads();
-    {
-        constexpr int N5 = (WV_PI * WV_PI + 3) / 4;
-        float mv[N5];
-        PARC_UNROLL
-        for (int it = 0; it < N5; ++it) { // 5x5 window = the four 3x3 windows at the diagonal offsets
-            const int i = w + 4 * it < WV_PI * WV_PI ? w + 4 * it : 0;
-            const int pi_ = i / WV_PI + 1, pj_ = i % WV_PI + 1; // centre (pi_+1, pj_+1) in patch cells = (pi_, pj_) in the 3x3 table
-            mv[it] = fmaxf(fmaxf(s_pmax3[((pi_ - 1) * WV_P3 + pj_ - 1) * 64], s_pmax3[((pi_ - 1) * WV_P3 + pj_ + 1) * 64]),
-                           fmaxf(s_pmax3[((pi_ + 1) * WV_P3 + pj_ - 1) * 64], s_pmax3[((pi_ + 1) * WV_P3 + pj_ + 1) * 64]));
-        }
-        PARC_UNROLL
-        for (int it = 0; it < N5; ++it) if (w + 4 * it < WV_PI * WV_PI) s_pmax[(w + 4 * it) * 64] = mv[it];
-    }
-    __syncthreads();
 
-    WSTAMP(0); // prologue: state load, height patch, running max
+    WSTAMP(0); // prologue: state load, height patch
     // ---- substeps.  The four waves of a block meet at NO barrier inside the loop: every hand-off is a record in LDS plus a
     // flag (the producer writes the record, then the flag: LDS operations of one wave complete in order; the consumer polls
     // the flag, then reads).  A wave waits only for what it really depends on:
@@ -1172,8 +1139,10 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
         WTL(15); // outward pass + integration of the own limb done
     }
     // ---- write back -----------------------------------------------------------------------------------------------------
-    // The prep-record quaternions of the trunk joints (two spherical joints for the humanoid: ~800 instructions) are formed by the
-    // helper wave, which is through earlier than wave 0: wave 0 hands their dofs over in LDS (the attach-kinematics slots are dead by now).
+    // Wave 0 is the last wave out of the substep loop.  The prep-record work on its state -- the quaternions of the trunk joints (two
+    // spherical joints for the humanoid: ~800 instructions) and the heading terms of the root (atan2, two sin / cos pairs) -- is formed by
+    // two other waves (WaveTables::ep_*), which are through their own stores by then: wave 0 hands the dofs and the root rotation over in
+    // LDS (the attach-kinematics slots are dead by now) as its first action.
     const bool hand = prep != nullptr && W.helper >= 1;
     float *s_hand = s_attkin;
     if (hand && w == 0) {
@@ -1186,11 +1155,18 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
                 else if (jt == DJ_HINGE) s_hand[(3 * k) * 64] = hang;
             }
         }
+        s_hand[(3 * WV_MAXLEN) * 64] = rq.x; s_hand[(3 * WV_MAXLEN + 1) * 64] = rq.y; s_hand[(3 * WV_MAXLEN + 2) * 64] = rq.z; s_hand[(3 * WV_MAXLEN + 3) * 64] = rq.w;
         publish(WV_F_HAND, 0);
     }
     if (!env_ok) return;
     float *odp = buf.char_dof_pos + (size_t)D_ * e, *odv = buf.char_dof_vel + (size_t)D_ * e, *ocf = buf.contact_forces + 3 * (size_t)e * B_;
     float4 *pr = prep ? prep + (size_t)e * 16 : nullptr;
+    // slot 0 of the prep record: heading terms of the new root rotation (k_env_prep, lane 0)
+    auto heading_terms = [&](q4 q) __attribute__((always_inline)) {
+        const float heading = parc::calc_heading(make_float4(q.x, q.y, q.z, q.w));
+        const float4 hinv = parc::heading_quat_inv(heading);
+        prep[(size_t)e * 16] = make_float4(cosf(heading), sinf(heading), hinv.z, hinv.w);
+    };
     if (w == 0) {
         const v3 out = mk(anc.x + rp.x, anc.y + rp.y, anc.z + rp.z);
         float *o = buf.char_root_pos + 3 * (size_t)e; o[0] = out.x; o[1] = out.y; o[2] = out.z;
@@ -1200,11 +1176,7 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
             sh[3] = rp.x - (out.x - anc.x); sh[4] = rp.y - (out.y - anc.y); sh[5] = rp.z - (out.z - anc.z);
         }
         o = buf.char_root_rot + 4 * (size_t)e; o[0] = rq.x; o[1] = rq.y; o[2] = rq.z; o[3] = rq.w;
-        if (prep) { // slot 0 of the prep record: heading terms of the new root rotation (k_env_prep, lane 0)
-            const float heading = parc::calc_heading(make_float4(rq.x, rq.y, rq.z, rq.w));
-            const float4 hinv = parc::heading_quat_inv(heading);
-            prep[(size_t)e * 16] = make_float4(cosf(heading), sinf(heading), hinv.z, hinv.w);
-        }
+        if (prep && !hand) heading_terms(rq);
         o = buf.char_root_vel + 3 * (size_t)e; o[0] = rv.x; o[1] = rv.y; o[2] = rv.z;
         o = buf.char_root_ang_vel + 3 * (size_t)e; o[0] = rw.x; o[1] = rw.y; o[2] = rw.z;
     }
@@ -1213,17 +1185,23 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
         if (k < llen) wv_store_joint(M, W, W.body[lc][k], limb[k], odp, odv, ocf, pr);
         if (k < tlen) wv_store_joint(M, W, W.body[0][k], trunk[k], odp, odv, ocf, hand ? nullptr : pr);
     }
-    if (hand && w == W.helper) {
+    if (hand && (w == W.ep_trunk_wave || w == W.ep_head_wave)) {
         await(WV_F_HAND, 0);
-        PARC_UNROLL
-        for (int k = 0; k < WV_MAXLEN; ++k) {
-            const int b = W.body[0][k];
-            if (k < W.len[0] && b != 0) {
-                const int jt = W.c[b].jtype;
-                if (jt == DJ_SPHERICAL) pr[b] = parc::exp_map_to_quat(parc::mk3(s_hand[(3 * k) * 64], s_hand[(3 * k + 1) * 64], s_hand[(3 * k + 2) * 64]));
-                else if (jt == DJ_HINGE) pr[b] = parc::axis_angle_to_quat(parc::mk3(W.c[b].axis[0], W.c[b].axis[1], W.c[b].axis[2]), s_hand[(3 * k) * 64]);
-                else pr[b] = make_float4(0.f, 0.f, 0.f, 1.f);
+        if (w == W.ep_trunk_wave) {
+            PARC_UNROLL
+            for (int k = 0; k < WV_MAXLEN; ++k) {
+                const int b = W.body[0][k];
+                if (k < W.len[0] && b != 0) {
+                    const int jt = W.c[b].jtype;
+                    if (jt == DJ_SPHERICAL) pr[b] = parc::exp_map_to_quat(parc::mk3(s_hand[(3 * k) * 64], s_hand[(3 * k + 1) * 64], s_hand[(3 * k + 2) * 64]));
+                    else if (jt == DJ_HINGE) pr[b] = parc::axis_angle_to_quat(parc::mk3(W.c[b].axis[0], W.c[b].axis[1], W.c[b].axis[2]), s_hand[(3 * k) * 64]);
+                    else pr[b] = make_float4(0.f, 0.f, 0.f, 1.f);
+                }
             }
+        }
+        if (w == W.ep_head_wave) {
+            q4 q; q.x = s_hand[(3 * WV_MAXLEN) * 64]; q.y = s_hand[(3 * WV_MAXLEN + 1) * 64]; q.z = s_hand[(3 * WV_MAXLEN + 2) * 64]; q.w = s_hand[(3 * WV_MAXLEN + 3) * 64];
+            heading_terms(q);
         }
     }
     // A flag wait of this block hit its bound: some wave integrated a stale record.  Every wave checks as its LAST action (a wave that

@@ -524,6 +524,12 @@ class HipParkourEnv(base_env.BaseEnv):
         A block that saw one wrote NaN root positions for its envs (parc_dynamics_wave.hpp)."""
         return int(self._lib.parc_env_dynamics_timeouts(self._handle))
 
+    def dynamics_manifold_drops(self):
+        """Contact planes the dynamics kernel had no room for since the library was loaded (its per-lane plane list: LDS share + overflow
+        area; parc_dynamics_wave.hpp).  A dropped plane is one contact of a body that already has twenty others: not an error, but it
+        should not happen in practice -- the GPU tests assert 0 on the benchmark scenes (synchronises the device)."""
+        return int(self._lib.parc_env_dynamics_manifold_drops(self._handle))
+
     def check_health(self):
         """Raise when the dynamics kernel reported a hand-off timeout: the physics of this run cannot be trusted."""
         n = self.dynamics_timeouts()
@@ -536,7 +542,8 @@ class HipParkourEnv(base_env.BaseEnv):
         """dm_env.py:668-727, plus the health counter of the dynamics kernel (read here = every iters_per_output iterations:
         the query synchronises).  A non-zero counter aborts the run (scripts/run_tracker.py exits non-zero)."""
         info = dict(self._dm_extra_log_info())
-        info["Env_Health"] = {"Dynamics_Flag_Timeouts": float(self.check_health())}
+        info["Env_Health"] = {"Dynamics_Flag_Timeouts": float(self.check_health()),
+                              "Dynamics_Manifold_Drops": float(self.dynamics_manifold_drops())}
         return info
 
     def post_test_update(self):

@@ -95,6 +95,7 @@ def test_dynamics_at_bench_sizes(tmp_path, n, motions):
     assert np.quantile(sp, 0.99) < 1.0 and sp.max() < 30.0, (np.quantile(sp, 0.99), sp.max())   # after 8 s 99 % are at rest (measured q99 0.11 m/s); nobody is launched
     assert np.mean(np.abs(to_np(env._char_contact_forces)).reshape(n, -1).max(1) > 20 * mg) < 5e-3
     assert env._lib.parc_env_dynamics_timeouts(env._handle) == 0   # no flag wait between the waves of a block ever hit its bound
+    assert env.dynamics_manifold_drops() == 0                      # every contact plane found a slot (LDS share + overflow area of its wave)
 
 
 def test_wave_kernel_vs_coop_on_a_slice_of_the_cfg3_scene(tmp_path, monkeypatch):
@@ -455,5 +456,6 @@ def test_soak_full_step_at_65536_envs():
         env.reset_done()
     assert ended > 1000
     assert env.dynamics_timeouts() == 0
+    assert env.dynamics_manifold_drops() == 0
     fr = env.get_fail_rates().numpy()
     assert np.isfinite(fr).all() and fr.min() > 0.0 and fr.max() <= 1.0

@@ -26,15 +26,8 @@ for _ in range(10):
     if not hold: env.reset_done()
 torch.cuda.synchronize()
 env._lib.parc_env_debug_wave_hist(a)
-bn = list(env._kin_char_model.get_body_names()) + ["?"] * 16
 def row(b, k): return [int(a[(b * 4 + k) * 16 + i]) for i in range(16)]
-for b in range(15):
-    if sum(row(b, 2)) == 0: continue
-    s = row(b, 3)
-    print("%-16s flat/lane %.3f gen/lane %.3f" % (bn[b], s[0] / max(s[2], 1), s[1] / max(s[2], 1)))
-    for k, nm in enumerate(["max flat", "max gen ", "max both"]):
-        r = row(b, k); t = max(sum(r), 1)
-        print("   %s " % nm + " ".join("%5.1f" % (100.0 * x / t) for x in r))
-for w in range(3):
+for w in range(4):
     r = row(15, w); t = max(sum(r), 1)
-    print("wave %d total (max over lanes, %%): " % (w + 1) + " ".join("%5.1f" % (100.0 * x / t) for x in r))
+    print("wave %d: planes held after a discovery, largest lane of the wave (%% of waves, 0..15+): " % w + " ".join("%5.1f" % (100.0 * x / t) for x in r))
+print("drops", env._lib.parc_env_dynamics_manifold_drops(env._handle))

@@ -32,7 +32,7 @@ for _ in range(iters):
 torch.cuda.synchronize()
 env._lib.parc_env_debug_wave_stamps(a)
 nblk = (n + 63) // 64
-names = ["prologue", "P1 trunk FK", "wait1", "P2A limbs", "(cull pass)", "P2B", "(segments)", "P3 root", "wait4", "P4 limbs out", "epilogue",
+names = ["prologue", "P1 trunk FK", "wait1", "P2A limbs", "(plane eval)", "P2B", "(segments)", "P3 root", "wait4", "P4 limbs out", "epilogue",
          "(limb FK)", "(own inertia)", "(narrow points)", "(joint inward)", "(misc)"]
 # the bracketed slots are carved out of P2A / P2B / P3 (finer stamps inside the bodies); the phase slots then hold the remainder
 out = {}
