@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PARC_ABI_VERSION 4
+#define PARC_ABI_VERSION 5
 #define PARC_MAX_BODIES 16   /* 15 quats + root position share one 16-lane group */
 #define PARC_MAX_DOFS 40     /* dof velocities live in floats [88,128) of a 128-float frame record */
 #define PARC_MAX_TAR_STEPS 6 /* 2 + steps skeletons <= 8 lane groups of 8 */
@@ -139,6 +139,17 @@ typedef struct {
     /* `global_root_height_obs` (ig_parkour_env.py:84, passed on as compute_char_obs's root_height_obs, :904; false by default): the root
      * height is one more observation in FRONT of the character block (ig_char_env.py:620-622): every later offset moves by one. */
     int32_t global_root_height_obs;
+    /* `use_contact_info` (ig_parkour_env.py:72-73; true by default): false drops the target / character contact blocks of the observation
+     * (:927-946) and the contact term of the reward (:1032-1040).  `enable_tar_obs` (:83; true by default): false drops the look-ahead
+     * target block (mgdm_dm_util.py:482-493) and, with it, the target contact block (:928-930). */
+    int32_t use_contact_info, enable_tar_obs;
+    /* Developer / test switches, "key=value;key=value" (NULL or "" = none; the product never sets any).  They are part of the configuration
+     * so that a measurement can state them (parc_env_describe): the library reads no environment variable.
+     *   segments=none|capsules   drop the collision segments (all / the sole edges of boxes)      dtang=<float>   tangential contact damping
+     *   kernel=coop|thread       force one of the general dynamics kernels                         man_period=<n>  contact discovery every n substeps
+     *   no_residual=1            no root-position residual (precision test)                        ema_leader=1 | curriculum_two_launches=1
+     *                                                                                              force one of the curriculum launch paths */
+    const char *dev_options;
 } ParcEnvConfig;
 
 /* Motion clips as MotionLib._load_motion_file receives them (motion_lib.py:255-401); the library
@@ -263,6 +274,11 @@ int parc_env_profile_step(ParcEnv *env, const float *action_dev, void *stream, i
 
 /* The waves of a k_dynamics_wave block hand records to each other through LDS flags; a wait is bounded so that a protocol
  * error cannot hang the GPU.  Number of waits that ever hit the bound on this device (synchronises; must be 0; < 0 = error). */
+/* What this handle resolved to, "key=value;..." (dynamics kernel, envs per block, collision points / segments, contact parameters, manifold
+ * period and margins, curriculum path, the dev_options it was created with): bench.py records it with every measurement.  The string
+ * lives as long as the handle. */
+const char *parc_env_describe(ParcEnv *env);
+
 int parc_env_dynamics_timeouts(ParcEnv *env);
 /* Contact planes the dynamics kernel had no room for since the library was loaded (its per-lane plane list and overflow area were full):
  * must stay 0.  Synchronises the device. */

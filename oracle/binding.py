@@ -62,7 +62,8 @@ class OrcEnvCfg(C.Structure):
                 ("pose_termination", C.c_int), ("track_root", C.c_int), ("track_root_h", C.c_int),
                 ("ema_weight", C.c_float), ("env_offsets", f32p), ("motion_offsets", f32p),
                 ("terrains_per_motion", C.c_int), ("num_contact_bodies", C.c_int), ("contact_body_ids", C.c_int * 16),
-                ("termination_height", C.c_float), ("global_obs", C.c_int), ("root_height_obs", C.c_int)]
+                ("termination_height", C.c_float), ("global_obs", C.c_int), ("no_contact_info", C.c_int), ("no_tar_obs", C.c_int),
+                ("root_height_obs", C.c_int)]
 
 
 _STATE_F32 = ["char_root_pos", "char_root_rot", "char_root_vel", "char_root_ang_vel", "char_dof_pos",
@@ -273,7 +274,8 @@ class Oracle:
                  max_obs_h, reward_w, joint_err_w, dof_err_w, contact_weights, pose_termination_dist,
                  root_pos_termination_dist, root_rot_termination_angle, env_offsets, motion_offsets,
                  terrains_per_motion=1, enable_early_termination=True, pose_termination=True, track_root=True,
-                 track_root_h=True, ema_weight=0.01, contact_body_ids=(), termination_height=0.15, global_obs=False, global_root_height_obs=False):
+                 track_root_h=True, ema_weight=0.01, contact_body_ids=(), termination_height=0.15, global_obs=False, global_root_height_obs=False,
+                 use_contact_info=True, enable_tar_obs=True):
         cfg = OrcEnvCfg()
         keep = []
 
@@ -305,6 +307,8 @@ class Oracle:
         cfg.termination_height = termination_height
         cfg.global_obs = int(global_obs)
         cfg.root_height_obs = int(global_root_height_obs)
+        cfg.no_contact_info = int(not use_contact_info)
+        cfg.no_tar_obs = int(not enable_tar_obs)
         cfg._keep = keep
         return cfg
 

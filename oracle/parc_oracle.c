@@ -615,7 +615,8 @@ static void compute_obs1(const OrcChar *c, const OrcMotionLib *lib, const OrcEnv
     const int rh = cfg->root_height_obs ? 1 : 0;   /* compute_char_obs ig_char_env.py:620-622: [root_h] + obs */
     int char_w = rh + 6 + 3 + 3 + 6 * J + D + 3 * K;
     int tar_w = 3 + 6 + 6 * J + 3 * K;
-    int obs_w = char_w + S * tar_w + S * B + B + R;
+    const int has_tar = !cfg->no_tar_obs, has_ct = !cfg->no_contact_info;   /* ig_parkour_env.py:927-946: which blocks exist */
+    int obs_w = char_w + (has_tar ? S * tar_w : 0) + (has_tar && has_ct ? S * B : 0) + (has_ct ? B : 0) + R;
     float *obs = s->obs + (size_t)e * obs_w;
     float *const row = obs;
     obs += rh;                                      /* the character block as laid out without the root height */
@@ -653,12 +654,13 @@ static void compute_obs1(const OrcChar *c, const OrcMotionLib *lib, const OrcEnv
     /* DeepMimicEnv.compute_tar_obs dm_env.py:594-626 + fetch_tar_obs_data mgdm_dm_util.py:221 + compute_tar_obs :405 */
     float mt = s->time_buf[e] + s->time_offsets[e]; /* _get_motion_times:547 */
     float *tar = row + char_w;
-    float *tarc = tar + S * tar_w;
-    for (int si = 0; si < S; ++si) {
+    float *tarc = tar + (has_tar ? S * tar_w : 0);
+    float tarc_scratch[ORC_MAX_BODIES];
+    for (int si = 0; si < S && has_tar; ++si) {
         float tstep = (float)cfg->timestep_d * (float)cfg->tar_obs_steps[si]; /* timestep * tar_obs_steps (f32 tensor) */
         float t = mt + tstep;
         float trp[3], trr[4], tjr[ORC_MAX_BODIES * 4], tbp[ORC_MAX_BODIES * 3];
-        motion_frame1(lib, s->motion_ids[e], t, trp, trr, NULL, NULL, tjr, NULL, tarc + (size_t)si * B);
+        motion_frame1(lib, s->motion_ids[e], t, trp, trr, NULL, NULL, tjr, NULL, has_ct ? tarc + (size_t)si * B : tarc_scratch);
         move_to_motion_terrain(cfg, s, e, trp);
         fk1(c, trp, trr, tjr, tbp, NULL);
         float *o = tar + (size_t)si * tar_w;
@@ -687,9 +689,9 @@ static void compute_obs1(const OrcChar *c, const OrcMotionLib *lib, const OrcEnv
         }
     }
     /* char contacts ig_parkour_env.py:655-662 */
-    float *cc = tarc + (size_t)S * B;
-    for (int b = 0; b < B; ++b) cc[b] = norm3(s->contact_forces + 3 * ((size_t)e * B + b)) > 1e-5f ? 1.f : 0.f;
-    memcpy(cc + B, s->ray_hfs + (size_t)e * R, (size_t)R * sizeof(float));
+    float *cc = tarc + (has_tar && has_ct ? (size_t)S * B : 0);
+    for (int b = 0; b < B && has_ct; ++b) cc[b] = norm3(s->contact_forces + 3 * ((size_t)e * B + b)) > 1e-5f ? 1.f : 0.f;
+    memcpy(cc + (has_ct ? B : 0), s->ray_hfs + (size_t)e * R, (size_t)R * sizeof(float));
 }
 
 void orc_env_compute_obs(const OrcChar *c, const OrcMotionLib *lib, const OrcEnvCfg *cfg, OrcEnvState *s,
@@ -771,7 +773,7 @@ static void update_reward1(const OrcChar *c, const OrcEnvCfg *cfg, OrcEnvState *
     float csum = 0.f;
     for (int b = 0; b < B; ++b)
         csum = csum + contact_reward1(s->ref_contacts[(size_t)B * e + b], s->contact_forces + 3 * ((size_t)e * B + b), cfg->contact_weights[b]);
-    float contact_penalty = csum / (float)B;
+    float contact_penalty = cfg->no_contact_info ? 0.f : csum / (float)B;   /* ig_parkour_env.py:1032: only with use_contact_info */
     r = r + contact_penalty;
     s->reward[e] = r;
     float *rt = s->reward_terms;

@@ -75,6 +75,7 @@ struct StepParams {
     int N, B, J, D, K, S, R, M, T;
     int lds_wave_floats; // dynamic LDS per wave of k_env_post
     int global_obs, off_char; // read by the OBSVAR instantiations of k_env_post only
+    int obs_tar, obs_contact; // OBSVAR only: 0 = the target block (+ target contacts) / the contact blocks and the reward's contact term are off
     int obs_dim, off_dofvel, off_key, off_tar, tar_w, off_tarc, off_cc, off_hf;
     float dt_f, episode_length, min_obs_h, max_obs_h;
     float pose_w, vel_w, root_pos_w, root_vel_w, key_pos_w;
@@ -287,6 +288,8 @@ __global__ __launch_bounds__(256, 5) void k_env_post(const StepParams P, const i
     const int lane = threadIdx.x & 63;
     const bool GLOBALOBS = OBSVAR && P.global_obs != 0; // a compile-time false in the default instantiations
     const int oc = OBSVAR ? P.off_char : 0;              // offset of the character block (1 when the root height leads the row)
+    const bool TAROBS = !OBSVAR || P.obs_tar != 0;       // enable_tar_obs (ig_parkour_env.py:83): the look-ahead target block exists
+    const bool CONTACTOBS = !OBSVAR || P.obs_contact != 0; // use_contact_info (:72): contact blocks of the observation, contact term of the reward
     float *s_obs = s_obs_all + (size_t)wv * P.lds_wave_floats;
     float4 (*s_q)[16] = s_q_all[wv];
     float4 (*s_lq)[16] = s_lq_all[wv];
@@ -438,7 +441,7 @@ __global__ __launch_bounds__(256, 5) void k_env_post(const StepParams P, const i
     }
     if (lane >= 32 && lane < 32 + B) { // contact flags + clamped force norms (ig_parkour_env.py:655-662, mgdm_dm_util.py:505-508)
         const float n = norm3(mk3(aux0, aux1, aux2));
-        orow[P.off_cc + (lane - 32)] = n > 1e-5f ? 1.f : 0.f;
+        if (CONTACTOBS) orow[P.off_cc + (lane - 32)] = n > 1e-5f ? 1.f : 0.f;
         s_cfn[lane - 32] = fminf(n, 1.0f);
     }
 #pragma unroll
@@ -557,7 +560,7 @@ __global__ __launch_bounds__(256, 5) void k_env_post(const StepParams P, const i
                     float *o = P.buf.ref_root_pos + 3 * (size_t)e;
                     o[0] = res.x; o[1] = res.y; o[2] = res.z;
                 }
-            } else { // observation pieces (ig_char_env.py:582, mgdm_dm_util.py:405)
+            } else if (r == 0 || TAROBS) { // observation pieces (ig_char_env.py:582, mgdm_dm_util.py:405)
                 const int base = r == 0 ? 0 : P.off_tar + (r - 2) * P.tar_w;
                 if (i < B) {
                     const Q4 qq = (i == 0 && !GLOBALOBS) ? quat_mul(hinv, res) : res;
@@ -586,7 +589,7 @@ __global__ __launch_bounds__(256, 5) void k_env_post(const StepParams P, const i
                 if (s == 0) {
                     s_refct[bd] = v[k];
                     if (MIRROR && P.buf.ref_contacts) P.buf.ref_contacts[(size_t)e * B + bd] = v[k];
-                } else {
+                } else if (TAROBS && CONTACTOBS) {
                     orow[P.off_tarc + (s - 1) * B + bd] = v[k];
                 }
             }
@@ -652,7 +655,7 @@ __global__ __launch_bounds__(256, 5) void k_env_post(const StepParams P, const i
                 const V3 rl = GLOBALOBS ? rd : quat_rotate(hinv, rd);
                 const int o = P.off_key + 3 * kk;
                 s_obs[o] = rl.x; s_obs[o + 1] = rl.y; s_obs[o + 2] = rl.z;
-            } else {
+            } else if (TAROBS) {
                 const int r = row + 1;
                 const float4 kp = s_fk[32 + (r - 2) * 8 + s_tab.key_slot[s_tab.key_ids[kk]]], trp = s_q[r][15];
                 const V3 rd = mk3(kp.x - trp.x, kp.y - trp.y, kp.z - trp.z);
@@ -813,7 +816,7 @@ __global__ __launch_bounds__(256, 5) void k_env_post(const StepParams P, const i
             const float pose_r = __shfl(eval, rowbase, 64), vel_r = __shfl(eval, rowbase + 1, 64), root_pose_r = __shfl(eval, rowbase + 2, 64),
                         root_vel_r = __shfl(eval, rowbase + 3, 64), key_pos_r = __shfl(eval, rowbase + 4, 64);
             float rew = P.pose_w * pose_r + P.vel_w * vel_r + P.root_pos_w * root_pose_r + P.root_vel_w * root_vel_r + P.key_pos_w * key_pos_r;
-            const float contact_pen = csum / (float)B; // torch.mean over bodies (ig_parkour_env.py:1033)
+            const float contact_pen = (OBSVAR && P.obs_contact == 0) ? 0.f : csum / (float)B; // torch.mean over bodies (ig_parkour_env.py:1033); no term without use_contact_info (:1032)
             rew = rew + contact_pen;
             // done (compute_done + DeepMimicEnv.update_done dm_env.py:628-665)
             int done = PARC_DONE_NULL;
@@ -1576,6 +1579,20 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 
 #define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return fail(PARC_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(_e)); } while (0)
 
+// ParcEnvConfig::dev_options, "key=value;key=value"
+static std::string dev_opt(const ParcEnvConfig *cfg, const char *key) {
+    if (!cfg->dev_options) return "";
+    const std::string all = cfg->dev_options, k = std::string(key) + "=";
+    size_t at = 0;
+    while (at < all.size()) {
+        size_t end = all.find(';', at);
+        if (end == std::string::npos) end = all.size();
+        if (all.compare(at, k.size(), k) == 0) return all.substr(at + k.size(), end - at - k.size());
+        at = end + 1;
+    }
+    return "";
+}
+
 // k_dynamics_wave, envs per block.  A block's latency does not depend on how many of its 64 lanes carry an env, so when 64-env blocks
 // would leave half the CUs without one (a multi-GPU shard), 32-env blocks put the same work on twice the CUs: -5 % at 8 192 envs (less LDS
 // and memory traffic per block; the vector instructions themselves take as long with 32 lanes as with 64)
@@ -1590,6 +1607,7 @@ struct ParcEnv {
     bool done_list_fresh = false;     // a step has produced a done list that parc_env_reset_done has not consumed yet
     StepParams sp;
     float4 *d_prep = nullptr;
+    std::string dev_options_s, describe_s; // the dev_options this handle was created with (owned copy) / parc_env_describe
     float *d_man_ovf = nullptr;       // k_dynamics_wave: overflow area of the per-lane contact-plane lists, [blocks][4 waves][WV_MAN_OVF][8][64]
     float *d_root_shadow = nullptr;   // [N][6]: root position the dynamics last wrote + what that write rounded away (k_dynamics_wave)
     parcdyn::DynModel h_dyn;
@@ -1677,6 +1695,8 @@ extern "C" int parc_env_create(const ParcEnvConfig *cfg, ParcEnv **out) {
     ParcEnv *e = new (std::nothrow) ParcEnv();
     if (!e) return fail(PARC_ERR_INVALID, "out of host memory");
     e->cfg = *cfg;
+    e->dev_options_s = cfg->dev_options ? cfg->dev_options : "";
+    e->cfg.dev_options = e->dev_options_s.c_str();
     e->cfg.ray_points_host = nullptr; e->cfg.env_offsets_host = nullptr;
     e->B = m.num_bodies; e->J = e->B - 1; e->D = m.dof_size; e->K = cfg->num_key_bodies; e->S = cfg->num_tar_obs_steps;
     e->R = cfg->num_rays; e->N = cfg->num_envs;
@@ -1715,9 +1735,10 @@ extern "C" int parc_env_create(const ParcEnvConfig *cfg, ParcEnv **out) {
     sp.off_key = sp.off_dofvel + D;
     sp.off_tar = sp.off_key + 3 * K;
     sp.tar_w = 3 + 6 + 6 * J + 3 * K;
-    sp.off_tarc = sp.off_tar + S * sp.tar_w;
-    sp.off_cc = sp.off_tarc + S * B;
-    sp.off_hf = sp.off_cc + B;
+    sp.obs_tar = cfg->enable_tar_obs != 0; sp.obs_contact = cfg->use_contact_info != 0;
+    sp.off_tarc = sp.off_tar + (sp.obs_tar ? S * sp.tar_w : 0);          // ig_parkour_env.py:927-946: the blocks that exist, in this order
+    sp.off_cc = sp.off_tarc + (sp.obs_tar && sp.obs_contact ? S * B : 0);
+    sp.off_hf = sp.off_cc + (sp.obs_contact ? B : 0);
     sp.obs_dim = sp.off_hf + R;
     e->obs_dim = sp.obs_dim;
     for (int q = 0; q < S; ++q) sp.tstep[q] = dt_f * (float)cfg->tar_obs_steps[q];
@@ -1759,21 +1780,29 @@ extern "C" int parc_env_create(const ParcEnvConfig *cfg, ParcEnv **out) {
     if (cfg->enable_dynamics) {
         memset(&e->h_dyn, 0, sizeof(e->h_dyn));
         parcdyn::fill_dyn_model(e->h_dyn, cfg->model, cfg->dynamics, cfg->action_low, cfg->action_high);
-        // developer switches for ablation measurements (tools/kbench.py); the product never sets them
-        if (const char *sv = getenv("PARC_DYN_SEGMENTS")) { // "none": collision points only; "capsules": drop the sole edges of boxes
-            const std::string mode = sv;
-            parcdyn::DynModel &dm = e->h_dyn;
-            int keep = 0;
-            for (int k = 0; k < dm.nseg; ++k) {
-                const bool drop = mode == "none" || (mode == "capsules" && dm.seg_r[k] <= 0.011f);
-                if (drop) continue;
-                dm.seg_body[keep] = dm.seg_body[k]; dm.seg_r[keep] = dm.seg_r[k];
-                for (int a = 0; a < 3; ++a) { dm.seg_a[keep][a] = dm.seg_a[k][a]; dm.seg_b[keep][a] = dm.seg_b[k][a]; }
-                ++keep;
+        // developer switches for ablation measurements (ParcEnvConfig::dev_options; the product never sets them)
+        {
+            const std::string mode = dev_opt(cfg, "segments"); // "none": collision points only; "capsules": drop the sole edges of boxes
+            if (!mode.empty()) {
+                parcdyn::DynModel &dm = e->h_dyn;
+                int keep = 0;
+                for (int k = 0; k < dm.nseg; ++k) {
+                    const bool drop = mode == "none" || (mode == "capsules" && dm.seg_r[k] <= 0.011f);
+                    if (drop) continue;
+                    dm.seg_body[keep] = dm.seg_body[k]; dm.seg_r[keep] = dm.seg_r[k];
+                    for (int a = 0; a < 3; ++a) { dm.seg_a[keep][a] = dm.seg_a[k][a]; dm.seg_b[keep][a] = dm.seg_b[k][a]; }
+                    ++keep;
+                }
+                dm.nseg = keep;
             }
-            dm.nseg = keep;
+            const std::string dt_ = dev_opt(cfg, "dtang");
+            if (!dt_.empty()) e->h_dyn.dtang = (float)atof(dt_.c_str());
+            const std::string mp_ = dev_opt(cfg, "man_period"); // contact discovery every n substeps (1 = every substep, the round-3 behaviour)
+            if (!mp_.empty() && atoi(mp_.c_str()) >= 1) {
+                e->h_dyn.man_period = atoi(mp_.c_str());
+                e->h_dyn.spec_tv = 1.5f * (float)(e->h_dyn.man_period - 1) * e->h_dyn.dt;
+            }
         }
-        if (const char *sv = getenv("PARC_DYN_DTANG")) e->h_dyn.dtang = (float)atof(sv);
         if ((r = up((void **)&e->d_dyn, &e->h_dyn, sizeof(e->h_dyn))) != hipSuccess) {
             free_dev(e); delete e;
             return fail(PARC_ERR_HIP, std::string("device allocation failed: ") + hipGetErrorString(r));
@@ -1781,14 +1810,13 @@ extern "C" int parc_env_create(const ParcEnvConfig *cfg, ParcEnv **out) {
         // Kernel choice by tree shape: wave-per-limb (a trunk chain + <= 4 limb chains of <= 3 bodies, the humanoid),
         // else chain-parallel (<= 8 chains of <= 4 bodies), else thread-per-env.  PARC_DYN_KERNEL=coop|thread forces
         // one of the more general kernels (they are kept as fallbacks for other trees and as cross-checks).
-        const char *kk = getenv("PARC_DYN_KERNEL");
-        const std::string want = kk ? kk : "";
+        const std::string want = dev_opt(cfg, "kernel");
         const bool coop_ok = parcdyn::build_coop_tables(e->h_dyn, e->h_coop);
         e->use_wave = coop_ok && parcdyn::build_wave_tables(e->h_dyn, e->h_coop, e->h_wave) && want != "coop" && want != "thread";
         e->use_coop = coop_ok && !e->use_wave && want != "thread";
         if (e->use_wave) {
             r = up((void **)&e->d_wave, &e->h_wave, sizeof(e->h_wave));
-            if (r == hipSuccess && !getenv("PARC_DYN_NO_RESIDUAL")) { // (developer switch: the precision test measures the drift without it)
+            if (r == hipSuccess && dev_opt(cfg, "no_residual").empty()) { // (developer switch: the precision test measures the drift without it)
                 r = hipMalloc((void **)&e->d_root_shadow, sizeof(float) * 6 * N);
                 if (r == hipSuccess) r = hipMemset(e->d_root_shadow, 0xff, sizeof(float) * 6 * N); // NaN: matches no buffer value
             }
@@ -1806,8 +1834,8 @@ extern "C" int parc_env_create(const ParcEnvConfig *cfg, ParcEnv **out) {
             return fail(PARC_ERR_HIP, std::string("dynamics kernel setup failed: ") + hipGetErrorString(r));
         }
     }
-    e->force_ema_leader = getenv("PARC_EMA_LEADER") != nullptr;
-    e->force_two_launch_curriculum = getenv("PARC_CURRICULUM_TWO_LAUNCHES") != nullptr;
+    e->force_ema_leader = !dev_opt(cfg, "ema_leader").empty();
+    e->force_two_launch_curriculum = !dev_opt(cfg, "curriculum_two_launches").empty();
     for (auto &ev : e->ev) (void)hipEventCreate(&ev);
     sp.tables = e->d_tab; sp.ray_points = e->d_ray; sp.env_offsets = e->d_env_off;
     sp.ema_code = e->d_ema; sp.prep = e->d_prep;
@@ -2004,6 +2032,9 @@ static int launch_curriculum(ParcEnv *e, hipStream_t st) {
     return PARC_OK;
 }
 
+// an observation layout other than the default one: the OBSVAR instantiations of k_env_post decide it at run time
+static bool obs_variant(const ParcEnvConfig &c) { return c.global_obs || c.global_root_height_obs || !c.use_contact_info || !c.enable_tar_obs; }
+
 static bool wants_mirror(const ParcEnvBuffers &b) {
     return b.ref_root_pos || b.ref_root_rot || b.ref_root_vel || b.ref_root_ang_vel || b.ref_joint_rot || b.ref_dof_pos || b.ref_dof_vel ||
            b.ref_body_pos || b.ref_contacts || b.ray_hfs || b.tracking_error;
@@ -2017,7 +2048,7 @@ static int launch_post(ParcEnv *e, int mode, const int64_t *ids, int count, hipS
     if (mode == MODE_STEP && e->cfg.enable_dynamics && e->use_wave) prep_done = true; // k_dynamics_wave wrote the prep records with the state
     if (!prep_done) hipLaunchKernelGGL(k_env_prep, dim3((count + 3) / 4), dim3(64), 0, st, e->sp, ids, ids32, count_dev, count);
     const bool mirror = wants_mirror(e->sp.buf);
-    if (e->cfg.global_obs || e->cfg.global_root_height_obs) { // a non-default observation layout -- instantiated for the general (MIRROR) form only
+    if (obs_variant(e->cfg)) { // a non-default observation layout -- instantiated for the general (MIRROR) form only
         if (mode == MODE_STEP && !e->sp.track_root) hipLaunchKernelGGL((k_env_post<MODE_STEP, true, true, true>), dim3(grid), dim3(64 * ENVS_PER_BLOCK), lds, st, e->sp, ids, ids32, count_dev, count, bump);
         else if (mode == MODE_STEP) hipLaunchKernelGGL((k_env_post<MODE_STEP, true, false, true>), dim3(grid), dim3(64 * ENVS_PER_BLOCK), lds, st, e->sp, ids, ids32, count_dev, count, bump);
         else hipLaunchKernelGGL((k_env_post<MODE_OBS, true, false, true>), dim3(grid), dim3(64 * ENVS_PER_BLOCK), lds, st, e->sp, ids, ids32, count_dev, count, bump);
@@ -2485,6 +2516,29 @@ extern "C" int parc_env_get_frame_vel_tables(ParcEnv *e, float *root_vel, float 
     return PARC_OK;
 }
 
+extern "C" const char *parc_env_describe(ParcEnv *e) {
+    if (!e) return "";
+    char b[1024];
+    std::string d;
+    const char *dk = !e->cfg.enable_dynamics ? "none" : (e->use_wave ? "k_dynamics_wave" : (e->use_coop ? "k_dynamics_coop" : "k_dynamics"));
+    snprintf(b, sizeof(b), "dynamics_kernel=%s;", dk); d += b;
+    if (e->cfg.enable_dynamics) {
+        const parcdyn::DynModel &m = e->h_dyn;
+        snprintf(b, sizeof(b), "envs_per_block=%d;substeps=%d;substep_dt=%.9g;collision_points=%d;collision_segments=%d;kn=%g;dn=%g;dtang=%g;mu=%g;pen_cap=%g;"
+                 "manifold_period=%d;spec_m0=%g;spec_tv=%g;spec_max=%g;root_residual=%d;", e->use_wave ? wave_envs_per_block(e->N, e->num_cus) : (e->use_coop ? CO_ENVS : 64),
+                 m.nsub, (double)m.dt, m.ncol, m.nseg, (double)m.kn, (double)m.dn, (double)m.dtang, (double)m.mu, (double)m.pen_cap, m.man_period, (double)m.spec_m0,
+                 (double)m.spec_tv, (double)m.spec_max, e->d_root_shadow ? 1 : 0);
+        d += b;
+        if (e->use_wave) { snprintf(b, sizeof(b), "manifold_lds_slots=%d+%d+%d+%d;manifold_overflow_slots=%d;", e->h_wave.man_cap[0], e->h_wave.man_cap[1], e->h_wave.man_cap[2], e->h_wave.man_cap[3], WV_MAN_OVF); d += b; }
+    }
+    const bool small = e->M <= 64 && !e->force_ema_leader && e->N <= CURRICULUM_ONE_LAUNCH_MAX && (e->N & 7) == 0 && !e->force_two_launch_curriculum;
+    snprintf(b, sizeof(b), "curriculum=%s;post_kernel=%s;dev_options=%s", small ? "k_curriculum_small" : ((e->M <= 64 && !e->force_ema_leader) ? "k_done_scatter+k_fail_rate_ema" : "k_done_scatter+k_ema_first+k_ema_leader"),
+             e->bound ? parc_env_post_kernel(e) : "unbound", e->dev_options_s.empty() ? "none" : e->dev_options_s.c_str());
+    d += b;
+    e->describe_s = d;
+    return e->describe_s.c_str();
+}
+
 extern "C" int parc_env_dynamics_timeouts(ParcEnv *e) {
     if (!e) return fail(PARC_ERR_INVALID, "null env");
     unsigned int v = 0;
@@ -2514,7 +2568,7 @@ extern "C" const char *parc_env_dynamics_kernel(ParcEnv *e) {
 
 extern "C" const char *parc_env_post_kernel(ParcEnv *e) {
     if (!e || !e->bound) return "";
-    return (wants_mirror(e->sp.buf) || e->cfg.global_obs || e->cfg.global_root_height_obs) ? "k_env_post<MODE,true>" : "k_env_post<MODE,false>";
+    return (wants_mirror(e->sp.buf) || obs_variant(e->cfg)) ? "k_env_post<MODE,true>" : "k_env_post<MODE,false>";
 }
 
 #ifdef PARC_STAMPS

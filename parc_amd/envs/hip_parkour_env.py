@@ -88,7 +88,7 @@ class HipParkourEnv(base_env.BaseEnv):
     NAME = "hip_parkour"
 
     def __init__(self, config, num_envs, device, visualize=False, env_id_base=0, total_envs=None, seed=0,
-                 mirror_ref_state=True, enable_dynamics=None):
+                 mirror_ref_state=True, enable_dynamics=None, dev_options=None, env_offsets=None):
         super().__init__(visualize=False)
         self._start_compute_time = time.time()
         self._lib = L.load()
@@ -101,7 +101,7 @@ class HipParkourEnv(base_env.BaseEnv):
         env_config = config["env"]
         self._env_config = env_config
         self._scene = sc = scene_mod.build_scene(config, num_envs, _device_index(device), env_id_base, total_envs,
-                                                 seed=seed, enable_dynamics=enable_dynamics)
+                                                 seed=seed, enable_dynamics=enable_dynamics, dev_options=dev_options, env_offsets=env_offsets)
         self._kin_char_model = sc.char_model
         self._episode_length_val = env_config["episode_length"]
         self._control_freq = env_config["control_freq"]
@@ -518,6 +518,20 @@ class HipParkourEnv(base_env.BaseEnv):
         for i in range(q.shape[0]):
             info["Misc"]["Fail Rate at " + str(round(q[i].item() * 100.0)) + "% Quantile"] = at_q[i].item() * 100.0
         return info
+
+    def describe(self):
+        """What the library handle resolved to (dynamics kernel, block size, collision set, contact parameters, manifold period, curriculum
+        path, the developer switches it was created with) as a dict: bench.py records it with every measurement."""
+        txt = self._lib.parc_env_describe(self._handle).decode()
+        out = {}
+        for kv in txt.split(";"):
+            if "=" in kv:
+                k, v = kv.split("=", 1)
+                out[k] = v
+        i = txt.find("dev_options=")
+        if i >= 0:
+            out["dev_options"] = txt[i + len("dev_options="):]
+        return out
 
     def dynamics_timeouts(self):
         """Flag waits of the dynamics kernel that hit their bound since the library was loaded (must be 0; synchronises the device).

@@ -119,8 +119,34 @@ def fill_dynamics(dp: L.ParcDynamicsParams, cm: CharModel, env_config: dict, sim
     dp.max_angular_velocity = 100.0
 
 
+# Developer / test switches of the library (ParcEnvConfig.dev_options).  The library itself reads no environment variable; the tools and
+# tests may still say PARC_DEV_OPTIONS="key=value;..." or use the round-3 variable names, which are translated HERE, on the Python side.
+_LEGACY_DEV_ENV = {"PARC_DYN_SEGMENTS": "segments", "PARC_DYN_DTANG": "dtang", "PARC_DYN_KERNEL": "kernel", "PARC_DYN_NO_RESIDUAL": "no_residual",
+                   "PARC_EMA_LEADER": "ema_leader", "PARC_CURRICULUM_TWO_LAUNCHES": "curriculum_two_launches", "PARC_DYN_MANIFOLD_PERIOD": "man_period"}
+
+
+def format_dev_options(dev_options=None):
+    """dict / "k=v;k=v" string (+ the environment, see above) -> the bytes ParcEnvConfig.dev_options points at (None = no switch set)."""
+    opts = {}
+    for var, key in _LEGACY_DEV_ENV.items():
+        if os.environ.get(var) is not None:
+            opts[key] = os.environ[var]
+    for src in (os.environ.get("PARC_DEV_OPTIONS"), dev_options):
+        if isinstance(src, dict):
+            opts.update({str(k): str(v) for k, v in src.items()})
+        elif src:
+            for kv in str(src).split(";"):
+                if "=" in kv:
+                    k, v = kv.split("=", 1)
+                    opts[k.strip()] = v.strip()
+    opts = {k: v for k, v in opts.items() if not (k == "kernel" and v == "wave")}   # "wave" = the default choice
+    if not opts:
+        return None
+    return ";".join(f"{k}={v}" for k, v in sorted(opts.items())).encode()
+
+
 def build_scene(config: dict, num_envs: int, device_index: int = 0, env_id_base: int = 0, total_envs=None,
-                seed: int = 0, enable_dynamics=None, verbose=True) -> Scene:
+                seed: int = 0, enable_dynamics=None, verbose=True, dev_options=None, env_offsets=None) -> Scene:
     env_config = config["env"]
     dm_config = env_config["dm"]
 
@@ -129,10 +155,8 @@ def build_scene(config: dict, num_envs: int, device_index: int = 0, env_id_base:
     if min(int(fraction_dm_envs * num_envs), num_envs) != num_envs:
         raise ValueError("fraction_dm_envs < 1 is not supported: every env is a DeepMimic env")
     _ = env_config["contact_detection_eps"]  # read but unused by the reference too (ig_parkour_env.py:55,655)
-    if not env_config["use_contact_info"]:
-        raise ValueError("use_contact_info: false is not supported")
-    if not env_config.get("enable_tar_obs", True):
-        raise ValueError("enable_tar_obs: false is not supported")
+    use_contact_info = bool(env_config["use_contact_info"])      # ig_parkour_env.py:72
+    enable_tar_obs = bool(env_config.get("enable_tar_obs", True))  # :83
     if env_config.get("control_mode", "pd") != "pd":
         raise ValueError("only control_mode: pd is supported")
     _ = env_config["debug_visuals"], env_config["ref_char_offset"], env_config["camera_mode"]
@@ -150,6 +174,9 @@ def build_scene(config: dict, num_envs: int, device_index: int = 0, env_id_base:
     ray = terrain.get_xy_points_cone(env_config["ray_dx"], env_config["ray_points_behind"], env_config["ray_points_ahead"],
                                      env_config["ray_num_left"], env_config["ray_num_right"], env_config["ray_angle"])
     env_off = env_offsets_square(num_envs, env_config["env_spacing"], env_id_base, total_envs)
+    if env_offsets is not None:  # test hook: env origins given by the caller (the far-origin parity fixture) instead of the square layout
+        env_off = np.ascontiguousarray(env_offsets, np.float32)
+        assert env_off.shape == (num_envs, 3)
     act_low, act_high = build_action_bounds_pd(cm)
     jw, dw = parse_joint_err_weights(cm, env_config.get("joint_err_w", None))
 
@@ -250,14 +277,20 @@ def build_scene(config: dict, num_envs: int, device_index: int = 0, env_id_base:
     cfg.global_obs = int(bool(env_config["global_obs"]))   # ig_parkour_env.py:83
     # _compute_obs passes root_height_obs=self._global_root_height_obs (ig_parkour_env.py:904): one more observation in front
     cfg.global_root_height_obs = int(bool(env_config["global_root_height_obs"]))
+    cfg.use_contact_info = int(use_contact_info)
+    cfg.enable_tar_obs = int(enable_tar_obs)
+    cfg.dev_options = format_dev_options(dev_options)
 
     from collections import OrderedDict
     J, K, S, R = B - 1, len(key_body_ids), len(tar_obs_steps), ray.shape[0]
     obs_shapes = OrderedDict()  # ig_parkour_env.py:911-958
     obs_shapes["char_obs"] = {"use_normalizer": True, "shape": (int(bool(env_config["global_root_height_obs"])) + 6 + 3 + 3 + 6 * J + D + 3 * K,)}
-    obs_shapes["tar_obs"] = {"use_normalizer": True, "shape": (S, 3 + 6 + 6 * J + 3 * K)}
-    obs_shapes["tar_contacts"] = {"use_normalizer": False, "shape": (S, B)}
-    obs_shapes["char_contacts"] = {"use_normalizer": False, "shape": (B,)}
+    if enable_tar_obs:
+        obs_shapes["tar_obs"] = {"use_normalizer": True, "shape": (S, 3 + 6 + 6 * J + 3 * K)}
+    if use_contact_info:
+        if enable_tar_obs:
+            obs_shapes["tar_contacts"] = {"use_normalizer": False, "shape": (S, B)}
+        obs_shapes["char_contacts"] = {"use_normalizer": False, "shape": (B,)}
     obs_shapes["hf"] = {"use_normalizer": False, "shape": (R,)}
 
     return Scene(cfg=cfg, char_model=cm, clips=clips, packed=packed, grid=grid, ray_points=ray, env_offsets=env_off,

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # PARC_ENV_LIB: developer override used to A/B kernel builds; the shipped library is the in-tree one
 LIB_PATH = os.environ.get("PARC_ENV_LIB") or os.path.join(_HERE, "libparc_env.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_BODIES, MAX_DOFS, MAX_TAR_STEPS, MAX_KEY, MAX_FK_PATHS, MAX_FK_DEPTH, MAX_GEOMS = 16, 40, 6, 8, 8, 8, 24
 
 f32p = C.POINTER(C.c_float)
@@ -59,7 +59,8 @@ class ParcEnvConfig(C.Structure):
                 ("env_offsets_host", f32p), ("action_low", C.c_float * MAX_DOFS), ("action_high", C.c_float * MAX_DOFS),
                 ("body_pos_from_fk", C.c_int32), ("enable_dynamics", C.c_int32), ("dynamics", ParcDynamicsParams),
                 ("seed", C.c_uint64), ("contact_body_mask", C.c_uint32), ("termination_height", C.c_float),
-                ("global_obs", C.c_int32), ("global_root_height_obs", C.c_int32)]
+                ("global_obs", C.c_int32), ("global_root_height_obs", C.c_int32),
+                ("use_contact_info", C.c_int32), ("enable_tar_obs", C.c_int32), ("dev_options", C.c_char_p)]
 
 
 class ParcMotionClips(C.Structure):
@@ -145,6 +146,8 @@ def load():
     lib.parc_env_dynamics_kernel.argtypes = [vp]
     lib.parc_env_set_never_done.argtypes = [vp, C.c_int32]
     lib.parc_env_dynamics_timeouts.argtypes = [vp]
+    lib.parc_env_describe.argtypes = [vp]
+    lib.parc_env_describe.restype = C.c_char_p
     lib.parc_env_dynamics_manifold_drops.argtypes = [vp]
     lib.parc_test_quat_op.argtypes = [C.c_int32, vp, vp, vp, C.c_int32, vp, vp]
     lib.parc_env_dynamics_kernel.restype = C.c_char_p
@@ -161,7 +164,7 @@ EXPORTED_SYMBOLS = [
     "parc_env_get_motion_info", "parc_env_set_rand_reset", "parc_env_set_start_time_fraction", "parc_dof_to_rot",
     "parc_rot_to_dof", "parc_forward_kinematics", "parc_calc_motion_frame", "parc_env_get_frame_vel_tables",
     "parc_env_profile_step", "parc_env_last_dynamics_ms", "parc_env_dynamics_kernel", "parc_env_set_kernel_timing", "parc_env_get_kernel_timing", "parc_env_record_bind", "parc_env_record_frame", "parc_env_set_episode_length", "parc_td_lambda_return", "parc_normalize_record", "parc_env_bind_action", "parc_env_get_buffers", "parc_env_step_reset_graph",
-    "parc_test_quat_op", "parc_build_flags", "parc_env_set_never_done", "parc_env_dynamics_timeouts", "parc_env_dynamics_manifold_drops",
+    "parc_test_quat_op", "parc_build_flags", "parc_env_set_never_done", "parc_env_dynamics_timeouts", "parc_env_dynamics_manifold_drops", "parc_env_describe",
     "parc_env_post_kernel",
 ]
 

@@ -370,10 +370,10 @@ def build_harness(m, clips, num_envs, cfg):
     env._pose_termination = env_config_.get("pose_termination", False)
     env._pose_termination_dist = torch.tensor(env_config_["pose_termination_dist"], dtype=torch.float32)
     env._tar_obs_steps = torch.tensor(env_config_["tar_obs_steps"], dtype=torch.int)
-    env._use_contact_info = True
+    env._use_contact_info = bool(env_config_["use_contact_info"])
     env._contact_weights = torch.tensor(env_config_["contact_weights"], dtype=torch.float32)
     env._debug_visuals = False
-    env._enable_tar_obs = True
+    env._enable_tar_obs = bool(env_config_.get("enable_tar_obs", True))
     env._global_root_height_obs = env_config_["global_root_height_obs"]
     env._track_root = env_config_["track_root"]
     env._track_root_h = env_config_["track_root_h"]
@@ -427,7 +427,10 @@ def build_harness(m, clips, num_envs, cfg):
     env._actors_need_reset = torch.zeros(num_envs, 1, dtype=torch.bool)
     env._info = dict()
     env._give_data_buffer_views()
-    env._obs_buf = z(num_envs, 1312 + int(bool(env_config_["global_root_height_obs"])))  # root_height_obs leads the row (ig_char_env.py:620)
+    # row width (ig_parkour_env.py:911-958): char 136 (+1: root_height_obs leads the row, ig_char_env.py:620) | tar 6 x 105 | tar contacts 6 x 15 |
+    # char contacts 15 | hf 441; `enable_tar_obs: false` drops the two target blocks, `use_contact_info: false` the two contact blocks
+    env._obs_buf = z(num_envs, 136 + int(bool(env_config_["global_root_height_obs"])) + (630 if env._enable_tar_obs else 0)
+                     + (90 if env._enable_tar_obs and env._use_contact_info else 0) + (15 if env._use_contact_info else 0) + 441)
     # Isaac Gym refresh calls are no-ops here: the caller injects the sim tensors
     env._refresh_sim_tensors = lambda: ipe.IGParkourEnv._refresh_obs_hfs(env)
     env.write_agent_states = lambda: None
@@ -664,6 +667,74 @@ def gen_env_step_global_obs(m):
     save("env_step_global_obs", **arrs)
 
 
+def gen_env_step_obs_blocks(m):
+    """`use_contact_info: false` (ig_parkour_env.py:72-73: no contact blocks in the observation :927-946, no contact term in the reward
+    :1032-1040) and `enable_tar_obs: false` (:83: no target block, mgdm_dm_util.py:482-493, and no target-contact block :928-930), each alone
+    and both together.  Same scene and reset as env_step.npz; the reset observation and one step on injected state."""
+    for uci, eto in ((False, True), (True, False), (False, False)):
+        cfg = env_config()
+        cfg["env"]["use_contact_info"] = uci
+        cfg["env"]["enable_tar_obs"] = eto
+        n = 64
+        env, dm = build_harness(m, CLIPS, n, cfg)
+        assert env._use_contact_info is uci and env._enable_tar_obs is eto
+        g = torch.Generator().manual_seed(61)
+        torch.manual_seed(67)
+        dm.reset(torch.arange(n))
+        env._refresh_sim_tensors()
+        env._update_observations(torch.arange(n))
+        arrs = {"use_contact_info": np.int32(uci), "enable_tar_obs": np.int32(eto), "reset_obs": npy(env._obs_buf)}
+        arrs.update(state_dict(env, dm, "reset_"))
+        env._timestep_buf[:] = torch.randint(1, 40, (n,), generator=g, dtype=torch.int32)
+        inject_state(env, dm, m, g, noise=0.02, big_noise_rows=(6, 7, 8, 9))
+        arrs.update(state_dict(env, dm, "in_"))
+        ig_env.IGEnv._post_physics_step(env)
+        arrs.update(out_dict(env, dm, "out_"))
+        save("env_step_obs_blocks_c%d_t%d" % (int(uci), int(eto)), **arrs)
+        print("obs blocks fixture", uci, eto, "obs width", env._obs_buf.shape[1], "reward terms", sorted(env._info["rewards"].keys()))
+
+
+def gen_env_step_far(m):
+    """The 64-env scene of env_step.npz with the env origins moved out to where the envs of a 65 536-env run sit (ig_parkour_env.py:389-398:
+    env_spacing * 2 * column, up to ~1 km): rows 0..31 by (+300 m, +300 m), rows 32..63 by (+1000 m, +700 m).  The env-local root
+    positions (dm_env.py:554-558: motion position + terrain offset - env offset) are then hundreds of metres, where one fp32 ulp is
+    3e-5 .. 6e-5 m: this fixture is what the REFERENCE's own arithmetic produces there -- the large-N allowance of the GPU parity tests
+    (1e-5 + 2 ulp of the coordinates) is checked against it instead of argued."""
+    cfg = env_config()
+    n = 64
+    env, dm = build_harness(m, CLIPS, n, cfg)
+    env._env_offsets[:32, 0] += 300.0; env._env_offsets[:32, 1] += 300.0       # in place: the DeepMimic env holds a view of the same tensor
+    env._env_offsets[32:, 0] += 1000.0; env._env_offsets[32:, 1] += 700.0
+    assert dm._env_offsets.data_ptr() == env._env_offsets.data_ptr() and torch.equal(dm._env_offsets, env._env_offsets)
+    g = torch.Generator().manual_seed(71)
+    torch.manual_seed(73)
+    dm.reset(torch.arange(n))
+    env._refresh_sim_tensors()
+    env._update_observations(torch.arange(n))
+    arrs = {"env_offsets": npy(env._env_offsets), "reset_obs": npy(env._obs_buf)}
+    arrs.update(state_dict(env, dm, "reset_"))
+    env._timestep_buf[:] = torch.randint(1, 40, (n,), generator=g, dtype=torch.int32)
+    inject_state(env, dm, m, g, noise=0.02, big_noise_rows=(6, 7, 8, 9))
+    arrs.update(state_dict(env, dm, "in_"))
+    ig_env.IGEnv._post_physics_step(env)
+    arrs.update(out_dict(env, dm, "out_"))
+    save("env_step_far", **arrs)
+    print("far fixture: |root| max", float(env._char_root_pos.abs().max()), "done histogram", np.bincount(npy(env._done_buf), minlength=4))
+
+
+def gen_action_bounds(m):
+    """IGCharEnv._build_action_bounds_pd (ig_char_env.py:307-347) on a bare instance: Isaac Gym's get_actor_dof_properties is replaced by the
+    joint limits the reference's own KinCharModel parsed from the MJCF (radians; what Isaac Gym reports for the same asset)."""
+    obj = object.__new__(ig_char_env.IGCharEnv)
+    obj._envs = [None]
+    obj._kin_char_model = m
+    obj._get_char_actor_handle = lambda: 0
+    lo, hi = npy(m._lower_dof_limits).astype(np.float32), npy(m._upper_dof_limits).astype(np.float32)
+    obj._gym = types.SimpleNamespace(get_actor_dof_properties=lambda env_handle, char_handle: {"lower": lo, "upper": hi})
+    low, high = ig_char_env.IGCharEnv._build_action_bounds_pd(obj)
+    save("action_bounds", dof_lower=lo, dof_upper=hi, action_low=np.asarray(low), action_high=np.asarray(high))
+
+
 def gen_done_table():
     g = torch.Generator().manual_seed(5)
     n = 128
@@ -689,6 +760,11 @@ def gen_done_table():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:   # only the named fixtures, e.g. `make_golden.py env_step_far action_bounds` (the others stay as committed)
+        model = load_char()
+        for name in sys.argv[1:]:
+            globals()["gen_" + name](model)
+        sys.exit(0)
     export_data_files()
     gen_quat_ops()
     model = load_char()
@@ -704,3 +780,6 @@ if __name__ == "__main__":
     gen_env_step_local_root(model)
     gen_env_step_global_obs(model)
     gen_env_step_root_height_obs(model)
+    gen_env_step_obs_blocks(model)
+    gen_env_step_far(model)
+    gen_action_bounds(model)

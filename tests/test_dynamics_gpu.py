@@ -459,3 +459,44 @@ def test_soak_full_step_at_65536_envs():
     assert env.dynamics_manifold_drops() == 0
     fr = env.get_fail_rates().numpy()
     assert np.isfinite(fr).all() and fr.min() > 0.0 and fr.max() <= 1.0
+
+
+@pytest.mark.parametrize("kernel", ["wave", "coop", "thread"])
+def test_out_of_range_actions_equal_host_clipped_actions_bit_for_bit(kernel):
+    """SURVEY a23 on the device: `_apply_action` clips the action to the PD bounds before it becomes the joint targets
+    (ig_char_env.py:488-490).  The bounds the env hands to the library equal the reference's own `_build_action_bounds_pd` (golden fixture
+    action_bounds.npz, all 28 x 2 values, as float32), and a control step with actions far outside them equals, bit for bit, the step from
+    the same state with the actions clipped ON THE HOST to the golden bounds -- for each of the three dynamics kernels."""
+    import torch
+    from conftest import golden
+    from gpu_helpers import default_config
+    from parc_amd.envs.hip_parkour_env import HipParkourEnv
+    g = golden("action_bounds")
+    n = 2048
+    env = HipParkourEnv(default_config(), n, "cuda:0", False, seed=5, enable_dynamics=True, mirror_ref_state=False, dev_options={"kernel": kernel})
+    assert env.describe()["dynamics_kernel"] == {"wave": "k_dynamics_wave", "coop": "k_dynamics_coop", "thread": "k_dynamics"}[kernel]
+    lo32, hi32 = g["action_low"].astype(np.float32), g["action_high"].astype(np.float32)
+    assert np.array_equal(env._action_bound_low.cpu().numpy(), lo32) and np.array_equal(env._action_bound_high.cpu().numpy(), hi32)
+    gen = torch.Generator(device="cuda:0"); gen.manual_seed(9)
+    env.reset()
+    for _ in range(3):
+        env.step(_bench_actions(env, gen)); env.reset_done()
+    names = ("_char_root_pos", "_char_root_rot", "_char_root_vel", "_char_root_ang_vel", "_char_dof_pos", "_char_dof_vel", "_char_contact_forces",
+             "_char_rigid_body_pos", "_timestep_buf", "_time_buf", "_motion_ids", "_motion_terrain_ids", "_motion_time_offsets")
+    saved = {k: getattr(env, k).clone() for k in names}
+    lo, hi = env._action_bound_low, env._action_bound_high
+    raw = 0.5 * (hi + lo) + 3.0 * (hi - lo) * torch.randn(n, lo.shape[0], device="cuda:0", generator=gen)   # most entries far outside
+    assert float(((raw < lo) | (raw > hi)).float().mean()) > 0.7
+    clipped = torch.minimum(torch.maximum(raw, torch.from_numpy(lo32).to(raw.device)), torch.from_numpy(hi32).to(raw.device))
+    out = []
+    # (the first pass is a warm-up: only there does the root-position residual of the previous step still match the state -- after it
+    # every pass starts from restored buffers, whose residual the kernel discards by value comparison)
+    for act in (raw, raw, clipped):
+        for k in names:
+            getattr(env, k).copy_(saved[k])
+        env.step(act.contiguous())
+        torch.cuda.synchronize()
+        out.append({k: getattr(env, k).clone() for k in names[:8]} | {"obs": env._obs_buf.clone(), "reward": env._reward_buf.clone()})
+    for k in out[1]:
+        assert torch.equal(out[1][k], out[2][k]), k
+    assert torch.isfinite(out[1]["obs"]).all()

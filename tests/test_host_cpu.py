@@ -113,9 +113,19 @@ def test_scene_assembly_and_action_bounds():
     cfg = default_config(); cfg["env"]["global_root_height_obs"] = True   # one more observation in front (built since round 3)
     sc1 = scene.build_scene(cfg, 4, verbose=False)
     assert sc1.cfg.global_root_height_obs == 1 and sc1.obs_shapes["char_obs"]["shape"] == (137,)
-    cfg = default_config(); cfg["env"]["use_contact_info"] = False          # still rejected
+    cfg = default_config(); cfg["env"]["use_contact_info"] = False          # built since round 4: no contact blocks (ig_parkour_env.py:927-946)
+    sc2 = scene.build_scene(cfg, 4, verbose=False)
+    assert sc2.cfg.use_contact_info == 0 and list(sc2.obs_shapes) == ["char_obs", "tar_obs", "hf"]
+    cfg["env"]["enable_tar_obs"] = False
+    sc3 = scene.build_scene(cfg, 4, verbose=False)
+    assert sc3.cfg.enable_tar_obs == 0 and list(sc3.obs_shapes) == ["char_obs", "hf"] and sum(int(np.prod(v["shape"])) for v in sc3.obs_shapes.values()) == 136 + 441
+    cfg = default_config(); cfg["env"]["control_mode"] = "vel"               # the other control modes stay rejected
     with pytest.raises(ValueError):
         scene.build_scene(cfg, 4, verbose=False)
+    # developer switches travel in the config (ParcEnvConfig.dev_options), the library reads no environment variable
+    assert scene.format_dev_options(None) is None and scene.format_dev_options({"kernel": "wave"}) is None
+    assert scene.format_dev_options({"segments": "none", "dtang": 1e4}) == b"dtang=10000.0;segments=none"
+    assert scene.format_dev_options("kernel=coop; man_period=1") == b"kernel=coop;man_period=1"
     cfg = default_config(); del cfg["env"]["pose_w"]
     with pytest.raises(KeyError):   # required key, like the reference
         scene.build_scene(cfg, 4, verbose=False)

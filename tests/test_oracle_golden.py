@@ -1,5 +1,7 @@
 """Pin the CPU oracle (oracle/parc_oracle.c) against golden vectors produced by the REAL reference
 (tests/golden/make_golden.py).  CPU-only; tolerance 2e-6 unless a case states otherwise."""
+import os
+
 import numpy as np
 import pytest
 
@@ -370,3 +372,82 @@ def test_env_step_with_root_height_observation_vs_reference_golden(oracle, orc_c
     assert np.array_equal(st["done"], g["out_done"])
     np.testing.assert_array_equal(st["obs"][:, 0], st["char_root_pos"][:, 2])      # the leading column IS the root height
 
+
+
+@pytest.mark.parametrize("uci,eto", [(False, True), (True, False), (False, False)])
+def test_env_step_without_contact_info_or_target_blocks_vs_reference_golden(oracle, orc_char, uci, eto):
+    """`use_contact_info: false` (ig_parkour_env.py:72-73: no contact blocks in the observation :927-946, no contact term in the reward
+    :1032-1040) and `enable_tar_obs: false` (:83: no target block, no target-contact block), alone and together (rejected with an error
+    until round 4).  Fixtures: the reference's own `_post_physics_step` with those switches on the env_step.npz scene."""
+    from helpers import default_cfg, load_clips, load_state_into, make_orc_mlib
+    g = golden("env_step_obs_blocks_c%d_t%d" % (int(uci), int(eto)))
+    g0 = golden("env_step")
+    width = 136 + (630 if eto else 0) + (90 if eto and uci else 0) + (15 if uci else 0) + 441
+    assert int(g["use_contact_info"]) == int(uci) and int(g["enable_tar_obs"]) == int(eto) and g["out_obs"].shape[1] == width
+    n = g0["env_offsets"].shape[0]
+    clips = load_clips([str(c) for c in g0["clips"]])
+    lib = make_orc_mlib(oracle, orc_char, clips, [1.0, 1.5, 2.0, 2.5])
+    ter = oracle.make_terrain(g0["hf"], g0["hf_min_point"], g0["hf_dxdy"])
+    st = oracle.make_state(n, M=len(clips), obs_w=width)
+    cfg = default_cfg(oracle, n, g0["ray_points"], g0["env_offsets"], g0["motion_offsets"], use_contact_info=uci, enable_tar_obs=eto)
+    load_state_into(st, g, "in_")
+    oracle.env_post_physics_step(orc_char, lib, ter, cfg, st)
+    oracle.env_update_curriculum(lib, cfg, st)
+    np.testing.assert_allclose(st["obs"], g["out_obs"], atol=1e-5)
+    np.testing.assert_allclose(st["reward"], g["out_reward"], atol=1e-5)
+    assert np.array_equal(st["done"], g["out_done"])
+    np.testing.assert_array_equal(st["fail_rates"], g["out_fail_rates"])
+    assert ("out_r_contact_penalty" in g.files) == uci      # the reference has no such reward term without contact info
+    # the same state under the default switches: the character block and the rays are the same columns, moved
+    st2 = oracle.make_state(n, M=len(clips))
+    cfg2 = default_cfg(oracle, n, g0["ray_points"], g0["env_offsets"], g0["motion_offsets"])
+    load_state_into(st2, g, "in_")
+    oracle.env_post_physics_step(orc_char, lib, ter, cfg2, st2)
+    np.testing.assert_array_equal(st["obs"][:, :136], st2["obs"][:, :136])
+    np.testing.assert_array_equal(st["obs"][:, -441:], st2["obs"][:, -441:])
+    if not uci:
+        assert np.abs(st["reward"] - st2["reward"]).max() > 1e-3     # the contact penalty is gone
+
+
+def test_env_step_at_far_env_origins_vs_reference_golden(oracle, orc_char):
+    """The env_step.npz scene with the env origins moved out by 300 m / 1 km (where the envs of a 65 536-env run sit): env-local
+    root positions of hundreds of metres, one fp32 ulp = 3e-5 .. 6e-5 m.  The fixture is what the REFERENCE's own arithmetic produces there;
+    the oracle restates the same operation order and lands on the same quantised values: the plain 1e-5 bar holds (measured 4.8e-7), done
+    flags and fail rates exact.  The GPU test of the same fixture (tests/test_hip_parity.py) measures what the kernel's different operation
+    order costs there."""
+    from helpers import default_cfg, load_clips, load_state_into, make_orc_mlib
+    g = golden("env_step_far")
+    g0 = golden("env_step")
+    n = g0["env_offsets"].shape[0]
+    assert np.abs(g["in_char_root_pos"]).max() > 900.0
+    clips = load_clips([str(c) for c in g0["clips"]])
+    lib = make_orc_mlib(oracle, orc_char, clips, [1.0, 1.5, 2.0, 2.5])
+    ter = oracle.make_terrain(g0["hf"], g0["hf_min_point"], g0["hf_dxdy"])
+    st = oracle.make_state(n, M=len(clips))
+    cfg = default_cfg(oracle, n, g0["ray_points"], g["env_offsets"], g0["motion_offsets"])
+    load_state_into(st, g, "in_")
+    oracle.env_post_physics_step(orc_char, lib, ter, cfg, st)
+    oracle.env_update_curriculum(lib, cfg, st)
+    err = np.abs(st["obs"] - g["out_obs"])
+    assert err.max() <= 1e-5, (err.max(), np.unravel_index(err.argmax(), err.shape))     # measured: 4.8e-7 -- the plain bar, no ulp allowance
+    assert np.abs(st["reward"] - g["out_reward"]).max() <= 1e-5
+    assert np.array_equal(st["done"], g["out_done"])
+    np.testing.assert_array_equal(st["fail_rates"], g["out_fail_rates"])
+
+
+def test_action_bounds_vs_reference_golden():
+    """`_build_action_bounds_pd` (ig_char_env.py:307-347).  action_bounds.npz = the reference's own function on the joint limits
+    its KinCharModel parsed from the MJCF (Isaac Gym's get_actor_dof_properties stubbed to return them): all 28 x 2 values."""
+    from parc_amd.char_model import CharModel
+    from parc_amd.envs import scene
+    from conftest import DATA
+    g = golden("action_bounds")
+    cm = CharModel(os.path.join(DATA, "assets", "humanoid.xml"))
+    lo, hi = cm.dof_limits()
+    np.testing.assert_array_equal(np.asarray(lo, np.float32), g["dof_lower"])
+    np.testing.assert_array_equal(np.asarray(hi, np.float32), g["dof_upper"])
+    low, high = scene.build_action_bounds_pd(cm)
+    assert low.shape == (28,) and high.shape == (28,)
+    np.testing.assert_allclose(low, g["action_low"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(high, g["action_high"], rtol=0, atol=1e-7)
+    assert (high > low).all()
