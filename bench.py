@@ -57,6 +57,9 @@ def parse(argv=None):
                     help="1: step + reset_done as one hipGraph launch (parc_env_step_reset_graph); kernel timings are then taken from a short separate run")
     ap.add_argument("--dynamics", type=int, default=1, help="1: full step (rigid-body dynamics + contact), 0: kinematic step only")
     ap.add_argument("--ppo", type=int, default=0, help="1: add the 40 x 42.56 MB gradient all-reduces of a PPO iteration to every 32 steps (cfg 4)")
+    ap.add_argument("--kernel-sample-steps", type=int, default=200,
+                    help="UNTIMED steps after the timed region whose per-step hipEvent kernel durations give roofline.kernel_sample (median / p95): "
+                         "a thicker sample than a short --steps; `value` and ms_per_step never include them")
     return ap.parse_args(argv)
 
 
@@ -385,17 +388,41 @@ def worker(a):
         dt = float(t.item())
 
     # kernel durations over the timed region: hipEvents recorded on the launch stream by every parc_env_step
+    import numpy as np
+
+    def read_samples():
+        cap = 65536
+        bufs = [np.zeros(cap, np.float32) for _ in range(3)]
+        got = C.c_int32()
+        L.check(env._lib.parc_env_get_kernel_timing_samples(env._handle, *[b.ctypes.data_as(L.f32p) for b in bufs], cap, C.byref(got)))
+        k = min(int(got.value), cap)
+        return [b[:k].astype(np.float64) for b in bufs]
+
+    def stats(x):
+        return None if len(x) == 0 else {"n": int(len(x)), "mean": float(np.mean(x)), "median": float(np.median(x)), "p95": float(np.quantile(x, 0.95)),
+                                         "min": float(np.min(x)), "max": float(np.max(x))}
     dms, pms, nst = C.c_double(), C.c_double(), C.c_int32()
+    timed_samples = None if a.graph else read_samples()
     L.check(env._lib.parc_env_get_kernel_timing(env._handle, C.byref(dms), C.byref(pms), C.byref(nst)))
     L.check(env._lib.parc_env_set_kernel_timing(env._handle, 0))
     if a.graph:  # events are not part of the captured graph: time the kernels over 20 ordinary steps instead
         L.check(env._lib.parc_env_set_kernel_timing(env._handle, 1))
         for i in range(20):
             env.step(actions[i & 3]); env.reset_done()
+        timed_samples = read_samples()
         L.check(env._lib.parc_env_get_kernel_timing(env._handle, C.byref(dms), C.byref(pms), C.byref(nst)))
         L.check(env._lib.parc_env_set_kernel_timing(env._handle, 0))
     else:
         assert nst.value == a.steps
+    # a thicker, UNTIMED sample of the same kernels (the driver's --steps 20 is 15 ms of GPU time): per-step medians and p95
+    extra_samples = None
+    if a.kernel_sample_steps > 0:
+        L.check(env._lib.parc_env_set_kernel_timing(env._handle, 1))
+        for i in range(a.kernel_sample_steps):
+            env.step(actions[i & 3]); env.reset_done()
+        torch.cuda.synchronize()
+        extra_samples = read_samples()
+        L.check(env._lib.parc_env_set_kernel_timing(env._handle, 0))
     dyn_ms, post_ms = float(dms.value), float(pms.value)
 
     # Counter-derived figures come from the committed rocprofv3 --pmc passes (profiles/, collected on the 65 536-env
@@ -447,7 +474,16 @@ def worker(a):
             hbm_gbs = BYTES_DYN_KERNEL * n_local / (dyn_ms * 1e-3) / 1e9
             roof["dynamics_kernel"] = {"kernel": env._lib.parc_env_dynamics_kernel(env._handle).decode(), "kernel_ms": dyn_ms, "bound": "valu",
                                        "hbm": {"achieved": hbm_gbs, "frac": hbm_gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_env_step": BYTES_DYN_KERNEL}}
-    roof["whole_step_algorithmic_bytes"] = BYTES_DYNAMICS if dynamics_on else BYTES_KINEMATIC
+    whole_bytes = BYTES_DYNAMICS if dynamics_on else BYTES_KINEMATIC
+    roof["whole_step_algorithmic_bytes"] = whole_bytes
+    # SURVEY 8(d)'s figure for the PATH: algorithmic bytes of the whole step / wall time of the timed region, against the HBM peak
+    roof["hbm_whole_step_gbs"] = whole_bytes * n_total / (dt / a.steps) / 1e9 / world
+    roof["hbm_whole_step_frac"] = roof["hbm_whole_step_gbs"] / HBM_PEAK_GBS
+    names = ("dynamics_kernel_ms", "obs_kernel_ms", "curriculum_launches_ms")
+    roof["kernel_ms_timed_steps"] = {nm: stats(x) for nm, x in zip(names, timed_samples)}
+    if extra_samples is not None:
+        roof["kernel_sample"] = {"steps": a.kernel_sample_steps, "note": "untimed steps after the timed region, hipEvents on the launch stream, per step",
+                                 **{nm: stats(x) for nm, x in zip(names, extra_samples)}}
     out = {
         "metric": "env-steps/s", "value": n_total * a.steps / dt, "unit": "env-steps/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
@@ -456,11 +492,15 @@ def worker(a):
                                + f", {n_total} envs total = {n_local} per GPU, " + lib_desc + ", reset of finished envs included"
                                + (f", + {PPO_ALLREDUCES_PER_ITER} x {GRAD_BUCKET_FLOATS * 4 / 1e6:.2f} MB gradient all-reduces per {PPO_STEPS_PER_ITER} steps ({backend})" if a.ppo else ""),
                    "envs_per_gpu": n_local, "total_envs": n_total, "dynamics": dynamics_on, "parallelism": f"env-shard x{world}",
-                   "launch": "hipGraph (step + reset_done)" if a.graph else "stream launches"},
+                   "launch": "hipGraph (step + reset_done)" if a.graph else "stream launches",
+                   # what the library handle resolved to: dynamics kernel, envs per block, collision set, contact parameters, manifold
+                   # period and margins, curriculum path, and every developer switch it was created with (none in the product)
+                   "library": env.describe(), "library_abi": int(env._lib.parc_abi_version()), "library_build_flags": build[1], "library_csrc_sha16": build[0]},
         "roofline": roof,
     }
     timeouts = int(env._lib.parc_env_dynamics_timeouts(env._handle)) if dynamics_on else 0
     out["dynamics_timeouts"] = timeouts   # LDS-flag hand-offs of k_dynamics_wave that hit their bound: must be 0
+    out["dynamics_manifold_drops"] = env.dynamics_manifold_drops() if dynamics_on else 0   # contact planes that found no slot: expected 0
     if a.ppo:
         ms = [e0.elapsed_time(e1) for e0, e1 in coll_events]
         out["collective"] = {"backend": backend, "world": world, "allreduce_bytes": GRAD_BUCKET_FLOATS * 4, "allreduces_per_iter": PPO_ALLREDUCES_PER_ITER,

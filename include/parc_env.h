@@ -280,6 +280,9 @@ int parc_env_profile_step(ParcEnv *env, const float *action_dev, void *stream, i
 const char *parc_env_describe(ParcEnv *env);
 
 int parc_env_dynamics_timeouts(ParcEnv *env);
+/* The same two counters {flag-wait timeouts, manifold drops} as two words of host-mapped pinned memory that the first launch after every
+ * step refreshes: readable WITHOUT a synchronisation (stale by at most one step).  NULL when pinned memory could not be mapped. */
+const unsigned int *parc_env_health_words(ParcEnv *env);
 /* Contact planes the dynamics kernel had no room for since the library was loaded (its per-lane plane list and overflow area were full):
  * must stay 0.  Synchronises the device. */
 int parc_env_dynamics_manifold_drops(ParcEnv *env);
@@ -336,6 +339,9 @@ int parc_env_record_frame(ParcEnv *env, void *stream);
  * clears the record. */
 int parc_env_set_kernel_timing(ParcEnv *env, int32_t enable);
 int parc_env_get_kernel_timing(ParcEnv *env, double *dynamics_ms_avg, double *obs_ms_avg, int32_t *steps);
+/* Per-step samples of the same events (call before parc_env_get_kernel_timing, which clears them): dynamics kernel, observation kernel and
+ * the curriculum launches of up to `cap` recorded steps; *steps = steps recorded. */
+int parc_env_get_kernel_timing_samples(ParcEnv *env, float *dynamics_ms, float *obs_ms, float *curriculum_ms, int32_t cap, int32_t *steps);
 
 /* name of the dynamics kernel this handle launches ("k_dynamics_wave", "k_dynamics_coop", "k_dynamics"; "" when
  * dynamics is off).  The choice follows the shape of the kinematic tree (see parc_env_create). */

@@ -61,6 +61,8 @@ void orc_dyn_inflate(void *m, float eps) {
 }
 // test hook: substeps per control step (1: the reported contact force is the one evaluated AT the given pose); returns the old value
 int orc_dyn_set_nsub(void *m, int n) { DynModel *M = (DynModel *)m; const int old = M->nsub; M->nsub = n; return old; }
+// collision points / segments / geoms that did not fit the model's fixed tables (parc_env_create refuses a model with any)
+int orc_dyn_truncated(void *m) { return ((DynModel *)m)->truncated; }
 int orc_dyn_get_nseg(void *m) { return ((DynModel *)m)->nseg; }
 // counterfactual for the tests: drop the collision segments (points only, the round-2 contact geometry); returns the old count
 int orc_dyn_set_nseg(void *m, int n) { DynModel *M = (DynModel *)m; const int old = M->nseg; M->nseg = n; return old; }

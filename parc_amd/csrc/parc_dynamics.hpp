@@ -105,6 +105,8 @@ struct DynModel {
     float lim_k, lim_d;          // joint-limit penalty
     float max_ang_vel, ang_damping;
     float total_mass;
+    int truncated;               // collision points / segments / mass parts that did not fit the fixed tables (DYN_MAXC / DYN_MAXS / 64): the model
+                                 // would depend on the geom order -- parc_env_create refuses such a model
     float ext_acc[2];            // TEST HOOK of the host build (oracle/dyn_oracle.cpp): uniform horizontal acceleration, i.e. a tilted gravity
                                  // vector (a slope without tilting the heightfield).  Always 0 in the library: fill_dyn_model zeroes it and
                                  // only this header's reference statement reads it.
@@ -755,13 +757,14 @@ inline void build_mass_and_collision(DynModel &M, const GeomIn *g, int ng) {
     double m[DYN_MAXB] = {0}, mc[DYN_MAXB][3] = {{0}};
     struct Part { int body; double mass; double c[3]; double I[3][3]; };
     Part parts[64]; int np = 0;
-    M.ncol = 0; M.nseg = 0;
+    M.ncol = 0; M.nseg = 0; M.truncated = 0;
     auto add_seg = [&](int body, const double *a, const double *b, double r) {
-        if (M.nseg >= DYN_MAXS) return;
+        if (M.nseg >= DYN_MAXS) { ++M.truncated; return; }
         M.seg_body[M.nseg] = body; M.seg_r[M.nseg] = (float)r;
         for (int q = 0; q < 3; ++q) { M.seg_a[M.nseg][q] = (float)a[q]; M.seg_b[M.nseg][q] = (float)b[q]; }
         M.nseg++;
     };
+    if (ng > 64) M.truncated += ng - 64;
     for (int k = 0; k < ng && np < 64; ++k) {
         Part P; P.body = g[k].body;
         for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) P.I[a][b] = 0.0;
@@ -770,11 +773,13 @@ inline void build_mass_and_collision(DynModel &M, const GeomIn *g, int ng) {
             P.mass = g[k].density * 4.0 / 3.0 * PI * r * r * r;
             for (int a = 0; a < 3; ++a) { P.c[a] = g[k].pos[a]; P.I[a][a] = 0.4 * P.mass * r * r; }
             if (M.ncol < DYN_MAXC) { M.col_body[M.ncol] = P.body; for (int a = 0; a < 3; ++a) M.col_pos[M.ncol][a] = g[k].pos[a]; M.col_r[M.ncol] = (float)r; M.ncol++; }
+            else ++M.truncated;
         } else if (g[k].type == DG_BOX) {
             double a = g[k].size[0], b = g[k].size[1], c = g[k].size[2];
             P.mass = g[k].density * 8.0 * a * b * c;
             for (int q = 0; q < 3; ++q) P.c[q] = g[k].pos[q];
             P.I[0][0] = P.mass / 3.0 * (b * b + c * c); P.I[1][1] = P.mass / 3.0 * (a * a + c * c); P.I[2][2] = P.mass / 3.0 * (a * a + b * b);
+            if (M.ncol + 8 > DYN_MAXC) M.truncated += M.ncol + 8 - DYN_MAXC;
             for (int q = 0; q < 8 && M.ncol < DYN_MAXC; ++q) {
                 M.col_body[M.ncol] = P.body;
                 M.col_pos[M.ncol][0] = g[k].pos[0] + ((q & 1) ? (float)a : -(float)a);
@@ -807,6 +812,7 @@ inline void build_mass_and_collision(DynModel &M, const GeomIn *g, int ng) {
             double u[3] = {0, 0, 1};
             if (L > 1e-9) for (int q = 0; q < 3; ++q) u[q] = d[q] / L;
             for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) P.I[a][b] = (a == b ? Itr : 0.0) + (Iax - Itr) * u[a] * u[b];
+            if (M.ncol + 2 > DYN_MAXC) M.truncated += M.ncol + 2 - DYN_MAXC;
             for (int e = 0; e < 2 && M.ncol < DYN_MAXC; ++e) {
                 M.col_body[M.ncol] = P.body;
                 for (int q = 0; q < 3; ++q) M.col_pos[M.ncol][q] = e ? g[k].pos2[q] : g[k].pos[q];

@@ -888,7 +888,10 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
         // bounded: a protocol error must not hang the GPU, and must not go unnoticed: the block's envs are poisoned at the end (s_flag[15])
         // and the device counter is bumped here, in the cold path only
         while (__hip_atomic_load(&s_flag[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= sub) {
-            if (++spins == PARC_FLAG_SPIN_BOUND) {
+            // once a wait of this block has timed out the step is void (the epilogue poisons the block's envs): the waits that follow give
+            // up after 256 polls instead of spinning the full bound again -- a protocol error costs one bound per block, not one per wait
+            if ((++spins & 255) == 0 && spins != PARC_FLAG_SPIN_BOUND && __hip_atomic_load(&s_flag[15], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) break;
+            if (spins == PARC_FLAG_SPIN_BOUND) {
                 __hip_atomic_store(&s_flag[15], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (lane == 0) atomicAdd(&g_wave_timeouts, 1u);
                 break;

@@ -972,8 +972,19 @@ __device__ __forceinline__ void done_scatter_block(const unsigned char *__restri
         reset_count[1] = never_done ? 0 : s_base + total;  // envs parc_env_reset_done resets (never_done: flags are NULL, nobody)
     }
 }
+// The health counters of the dynamics kernel (flag waits that timed out, contact planes that found no slot) go to two words of
+// host-mapped pinned memory with the first launch after every step: the host reads them without a synchronisation or a copy
+// (HipParkourEnv.step looks at them every step: a protocol error aborts the run at the next step instead of at the next log interval).
+__device__ __forceinline__ void publish_health(unsigned int *health) {
+    if (health && blockIdx.x == 0 && threadIdx.x == 0) {
+        __builtin_nontemporal_store(parcdyn::g_wave_timeouts, health);
+        __builtin_nontemporal_store(parcdyn::g_wave_man_drops, health + 1);
+    }
+}
+
 __global__ __launch_bounds__(1024) void k_done_scatter(const unsigned char *__restrict__ ema_code, const int *__restrict__ motion_ids,
-                                                       int N, int *done_list, int *done_key, int *reset_count, int never_done) {
+                                                       int N, int *done_list, int *done_key, int *reset_count, int never_done, unsigned int *health) {
+    publish_health(health);
     done_scatter_block(ema_code, motion_ids, N, done_list, done_key, reset_count, never_done, blockIdx.x, gridDim.x);
 }
 
@@ -1114,7 +1125,8 @@ __global__ __launch_bounds__(1024) void k_fail_rate_ema(const int *__restrict__ 
 #define CURRICULUM_ONE_LAUNCH_MAX 8192 // measured: -1.6 us per step at 8 192 envs, +1.6 us at 16 384 (two passes of the scan)
 __global__ __launch_bounds__(1024) void k_curriculum_small(const unsigned char *__restrict__ ema_code, const int *__restrict__ motion_ids, int N,
                                                           int *done_list, int *done_key, int *reset_count, int never_done, int nchunks,
-                                                          float *fail_rates, int M, float w) {
+                                                          float *fail_rates, int M, float w, unsigned int *health) {
+    publish_health(health);
     if ((int)blockIdx.x < nchunks) {
         done_scatter_block(ema_code, motion_ids, N, done_list, done_key, reset_count, never_done, blockIdx.x, nchunks);
     } else {
@@ -1608,6 +1620,7 @@ struct ParcEnv {
     StepParams sp;
     float4 *d_prep = nullptr;
     std::string dev_options_s, describe_s; // the dev_options this handle was created with (owned copy) / parc_env_describe
+    unsigned int *h_health = nullptr, *d_health = nullptr; // two words of host-mapped pinned memory (publish_health) and their device alias
     float *d_man_ovf = nullptr;       // k_dynamics_wave: overflow area of the per-lane contact-plane lists, [blocks][4 waves][WV_MAN_OVF][8][64]
     float *d_root_shadow = nullptr;   // [N][6]: root position the dynamics last wrote + what that write rounded away (k_dynamics_wave)
     parcdyn::DynModel h_dyn;
@@ -1617,7 +1630,7 @@ struct ParcEnv {
     bool use_coop = false;
     parcdyn::WaveTables h_wave;
     parcdyn::WaveTables *d_wave = nullptr;
-    bool use_wave = false;
+    bool use_wave = false, wave_rejected = false;
     DevTables h_tab;
     DevTables *d_tab = nullptr;
     float *d_ray = nullptr, *d_env_off = nullptr, *d_hf = nullptr, *d_motion_off = nullptr;
@@ -1658,6 +1671,7 @@ static void free_dev(ParcEnv *e) {
                     e->d_cdf, e->d_ema, e->d_done_list, e->d_done_key, e->d_chunk_count, e->d_motion_done, e->d_reset_count, e->d_reset_calls,
                     e->d_scratch_jr};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (e->h_health) (void)hipHostFree(e->h_health);
     for (auto &ev : e->ev) if (ev) (void)hipEventDestroy(ev);
     for (auto &ev : e->tev) if (ev) (void)hipEventDestroy(ev);
     if (e->graph_exec) (void)hipGraphExecDestroy(e->graph_exec);
@@ -1780,6 +1794,12 @@ extern "C" int parc_env_create(const ParcEnvConfig *cfg, ParcEnv **out) {
     if (cfg->enable_dynamics) {
         memset(&e->h_dyn, 0, sizeof(e->h_dyn));
         parcdyn::fill_dyn_model(e->h_dyn, cfg->model, cfg->dynamics, cfg->action_low, cfg->action_high);
+        if (e->h_dyn.truncated > 0 || cfg->dynamics.num_geoms > PARC_MAX_GEOMS) { // a silently shortened collision set would depend on the geom order
+            const int t = e->h_dyn.truncated;
+            free_dev(e); delete e;
+            return fail(PARC_ERR_INVALID, "dynamics: " + std::to_string(t) + " collision point(s) / segment(s) / geom(s) do not fit the model tables (DYN_MAXC " +
+                        std::to_string(DYN_MAXC) + ", DYN_MAXS " + std::to_string(DYN_MAXS) + ", " + std::to_string(PARC_MAX_GEOMS) + " geoms)");
+        }
         // developer switches for ablation measurements (ParcEnvConfig::dev_options; the product never sets them)
         {
             const std::string mode = dev_opt(cfg, "segments"); // "none": collision points only; "capsules": drop the sole edges of boxes
@@ -1812,7 +1832,9 @@ extern "C" int parc_env_create(const ParcEnvConfig *cfg, ParcEnv **out) {
         // one of the more general kernels (they are kept as fallbacks for other trees and as cross-checks).
         const std::string want = dev_opt(cfg, "kernel");
         const bool coop_ok = parcdyn::build_coop_tables(e->h_dyn, e->h_coop);
-        e->use_wave = coop_ok && parcdyn::build_wave_tables(e->h_dyn, e->h_coop, e->h_wave) && want != "coop" && want != "thread";
+        const bool wave_ok = coop_ok && parcdyn::build_wave_tables(e->h_dyn, e->h_coop, e->h_wave);
+        e->wave_rejected = !wave_ok; // the tree / the collision tables do not fit k_dynamics_wave (parc_env_describe says so: the fallbacks are several times slower)
+        e->use_wave = wave_ok && want != "coop" && want != "thread";
         e->use_coop = coop_ok && !e->use_wave && want != "thread";
         if (e->use_wave) {
             r = up((void **)&e->d_wave, &e->h_wave, sizeof(e->h_wave));
@@ -1836,6 +1858,10 @@ extern "C" int parc_env_create(const ParcEnvConfig *cfg, ParcEnv **out) {
     }
     e->force_ema_leader = !dev_opt(cfg, "ema_leader").empty();
     e->force_two_launch_curriculum = !dev_opt(cfg, "curriculum_two_launches").empty();
+    if (hipHostMalloc((void **)&e->h_health, 2 * sizeof(unsigned int), hipHostMallocMapped) == hipSuccess) {
+        e->h_health[0] = 0u; e->h_health[1] = 0u;
+        if (hipHostGetDevicePointer((void **)&e->d_health, e->h_health, 0) != hipSuccess) e->d_health = nullptr;
+    }
     for (auto &ev : e->ev) (void)hipEventCreate(&ev);
     sp.tables = e->d_tab; sp.ray_points = e->d_ray; sp.env_offsets = e->d_env_off;
     sp.ema_code = e->d_ema; sp.prep = e->d_prep;
@@ -2014,12 +2040,12 @@ static int launch_curriculum(ParcEnv *e, hipStream_t st) {
     e->done_list_fresh = true;
     if (e->M <= 64 && !e->force_ema_leader && e->N <= CURRICULUM_ONE_LAUNCH_MAX && (e->N & 7) == 0 && !e->force_two_launch_curriculum) {
         hipLaunchKernelGGL(k_curriculum_small, dim3(e->nchunks + e->M), dim3(1024), 0, st, e->d_ema, e->sp.buf.motion_ids, e->N, e->d_done_list,
-                           e->d_done_key, e->d_reset_count, e->sp.never_done, e->nchunks, e->d_fail, e->M, e->cfg.fail_rate_ema_weight);
+                           e->d_done_key, e->d_reset_count, e->sp.never_done, e->nchunks, e->d_fail, e->M, e->cfg.fail_rate_ema_weight, e->d_health);
         HIPCHK(hipGetLastError());
         return PARC_OK;
     }
     hipLaunchKernelGGL(k_done_scatter, dim3(e->nchunks), dim3(1024), 0, st, e->d_ema, e->sp.buf.motion_ids, e->N, e->d_done_list,
-                       e->d_done_key, e->d_reset_count, e->sp.never_done);
+                       e->d_done_key, e->d_reset_count, e->sp.never_done, e->d_health);
     if (e->M <= 64 && !e->force_ema_leader) {
         hipLaunchKernelGGL(k_fail_rate_ema, dim3(e->M), dim3(1024), 0, st, e->d_done_key, e->d_reset_count, e->d_fail, e->M,
                            e->cfg.fail_rate_ema_weight);
@@ -2073,13 +2099,13 @@ extern "C" int parc_env_step(ParcEnv *e, const float *action_dev, void *stream) 
     hipStream_t st = (hipStream_t)stream;
     hipEvent_t *tv = nullptr;
     if (e->timing) { // no host synchronisation: events come from a growing pool and are read back by parc_env_get_kernel_timing
-        if (e->tev_used + 3 > e->tev.size()) {
+        if (e->tev_used + 4 > e->tev.size()) {
             const size_t old = e->tev.size();
-            e->tev.resize(old + 768, nullptr);
+            e->tev.resize(old + 1024, nullptr);
             for (size_t i = old; i < e->tev.size(); ++i) HIPCHK(hipEventCreate(&e->tev[i]));
         }
         tv = &e->tev[e->tev_used];
-        e->tev_used += 3;
+        e->tev_used += 4;
         HIPCHK(hipEventRecord(tv[0], st));
     }
     rc = launch_dynamics(e, action_dev, st);
@@ -2088,7 +2114,9 @@ extern "C" int parc_env_step(ParcEnv *e, const float *action_dev, void *stream) 
     rc = launch_post(e, MODE_STEP, nullptr, e->N, st);
     if (rc) return rc;
     if (tv) HIPCHK(hipEventRecord(tv[2], st));
-    return launch_curriculum(e, st);
+    rc = launch_curriculum(e, st);
+    if (tv) HIPCHK(hipEventRecord(tv[3], st));
+    return rc;
 }
 
 extern "C" int parc_env_get_buffers(ParcEnv *e, ParcEnvBuffers *out) {
@@ -2228,15 +2256,34 @@ extern "C" int parc_env_set_kernel_timing(ParcEnv *e, int32_t enable) {
     return PARC_OK;
 }
 
+// Per-step samples of the same events (call BEFORE parc_env_get_kernel_timing, which clears them): up to `cap` steps, dynamics kernel /
+// observation kernel / the curriculum launches that close the step.  Returns the number of steps recorded in *steps.
+extern "C" int parc_env_get_kernel_timing_samples(ParcEnv *e, float *dynamics_ms, float *obs_ms, float *curriculum_ms, int32_t cap, int32_t *steps) {
+    if (!e) return fail(PARC_ERR_INVALID, "null env");
+    const size_t n = e->tev_used / 4;
+    for (size_t i = 0; i < n && (int32_t)i < cap; ++i) {
+        float a = 0.f, b = 0.f, c = 0.f;
+        HIPCHK(hipEventSynchronize(e->tev[4 * i + 3]));
+        HIPCHK(hipEventElapsedTime(&a, e->tev[4 * i], e->tev[4 * i + 1]));
+        HIPCHK(hipEventElapsedTime(&b, e->tev[4 * i + 1], e->tev[4 * i + 2]));
+        HIPCHK(hipEventElapsedTime(&c, e->tev[4 * i + 2], e->tev[4 * i + 3]));
+        if (dynamics_ms) dynamics_ms[i] = a;
+        if (obs_ms) obs_ms[i] = b;
+        if (curriculum_ms) curriculum_ms[i] = c;
+    }
+    if (steps) *steps = (int32_t)n;
+    return PARC_OK;
+}
+
 extern "C" int parc_env_get_kernel_timing(ParcEnv *e, double *dynamics_ms_avg, double *obs_ms_avg, int32_t *steps) {
     if (!e) return fail(PARC_ERR_INVALID, "null env");
-    const size_t n = e->tev_used / 3;
+    const size_t n = e->tev_used / 4;
     double dyn = 0.0, post = 0.0;
     for (size_t i = 0; i < n; ++i) {
         float a = 0.f, b = 0.f;
-        HIPCHK(hipEventSynchronize(e->tev[3 * i + 2]));
-        HIPCHK(hipEventElapsedTime(&a, e->tev[3 * i], e->tev[3 * i + 1]));
-        HIPCHK(hipEventElapsedTime(&b, e->tev[3 * i + 1], e->tev[3 * i + 2]));
+        HIPCHK(hipEventSynchronize(e->tev[4 * i + 3]));
+        HIPCHK(hipEventElapsedTime(&a, e->tev[4 * i], e->tev[4 * i + 1]));
+        HIPCHK(hipEventElapsedTime(&b, e->tev[4 * i + 1], e->tev[4 * i + 2]));
         dyn += a; post += b;
     }
     if (dynamics_ms_avg) *dynamics_ms_avg = n ? dyn / (double)n : 0.0;
@@ -2516,6 +2563,8 @@ extern "C" int parc_env_get_frame_vel_tables(ParcEnv *e, float *root_vel, float 
     return PARC_OK;
 }
 
+extern "C" const unsigned int *parc_env_health_words(ParcEnv *e) { return (e && e->d_health) ? e->h_health : nullptr; }
+
 extern "C" const char *parc_env_describe(ParcEnv *e) {
     if (!e) return "";
     char b[1024];
@@ -2529,6 +2578,7 @@ extern "C" const char *parc_env_describe(ParcEnv *e) {
                  m.nsub, (double)m.dt, m.ncol, m.nseg, (double)m.kn, (double)m.dn, (double)m.dtang, (double)m.mu, (double)m.pen_cap, m.man_period, (double)m.spec_m0,
                  (double)m.spec_tv, (double)m.spec_max, e->d_root_shadow ? 1 : 0);
         d += b;
+        if (e->wave_rejected) d += "note=the model does not fit k_dynamics_wave (tree shape or > 32 candidates on a body): general fallback kernel;";
         if (e->use_wave) { snprintf(b, sizeof(b), "manifold_lds_slots=%d+%d+%d+%d;manifold_overflow_slots=%d;", e->h_wave.man_cap[0], e->h_wave.man_cap[1], e->h_wave.man_cap[2], e->h_wave.man_cap[3], WV_MAN_OVF); d += b; }
     }
     const bool small = e->M <= 64 && !e->force_ema_leader && e->N <= CURRICULUM_ONE_LAUNCH_MAX && (e->N & 7) == 0 && !e->force_two_launch_curriculum;

@@ -129,6 +129,8 @@ class HipParkourEnv(base_env.BaseEnv):
         # ---- library handle + tables ----------------------------------------------------------------
         self._handle = C.c_void_p()
         L.check(self._lib.parc_env_create(C.byref(sc.cfg), C.byref(self._handle)))
+        hw = self._lib.parc_env_health_words(self._handle)   # {flag-wait timeouts, manifold drops}: host-mapped, refreshed by every step
+        self._health = np.ctypeslib.as_array(hw, shape=(2,)) if hw else None
         p = sc.packed
         mc = L.ParcMotionClips()
         mc.num_motions = len(sc.clips)
@@ -276,6 +278,8 @@ class HipParkourEnv(base_env.BaseEnv):
             assert action.shape == (self._num_envs, self._char_dof_pos.shape[1]) and action.dtype == torch.float32
             a = action.contiguous().data_ptr()
         L.check(self._lib.parc_env_step(self._handle, a, self._stream()))
+        if self._health is not None and self._health[0] != 0:   # host-mapped counter of the dynamics kernel, refreshed by every step: no sync
+            self.check_health()
         self.write_agent_states()  # ig_parkour_env.py:686-696: after update_done, before the agent resets anything
         self._update_info()
         return self._obs_buf, self._reward_buf, self._done_buf, self._info
@@ -293,6 +297,8 @@ class HipParkourEnv(base_env.BaseEnv):
             if action.data_ptr() != self._action_buf.data_ptr():
                 self._action_buf.copy_(action)
         L.check(self._lib.parc_env_step_reset_graph(self._handle, self._stream()))
+        if self._health is not None and self._health[0] != 0:
+            self.check_health()
         self._update_info()
         return self._obs_buf, self._reward_buf, self._done_buf, self._info
 

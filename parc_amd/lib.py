@@ -103,6 +103,8 @@ def load():
     lib.parc_build_flags.restype = C.c_char_p
     flags = lib.parc_build_flags().decode()
     missing = [f for f in REQUIRED_BUILD_FLAGS if f not in flags.split()]
+    if any(m in flags for m in TEST_BUILD_MARKERS) and os.environ.get("PARC_ALLOW_TEST_BUILD") != "1":
+        raise RuntimeError(f"{LIB_PATH} is a test-only build ('{flags}'): the product never loads it")
     if missing:  # an SLP-vectorised k_dynamics_wave computes wrong inertias; contraction breaks the 1e-5 parity
         raise RuntimeError(f"{LIB_PATH} was built with '{flags}': missing {missing}; rebuild with __graft_entry__.build()")
     lib.parc_last_error.restype = C.c_char_p
@@ -147,6 +149,9 @@ def load():
     lib.parc_env_set_never_done.argtypes = [vp, C.c_int32]
     lib.parc_env_dynamics_timeouts.argtypes = [vp]
     lib.parc_env_describe.argtypes = [vp]
+    lib.parc_env_health_words.argtypes = [vp]
+    lib.parc_env_health_words.restype = C.POINTER(C.c_uint32)
+    lib.parc_env_get_kernel_timing_samples.argtypes = [vp, f32p, f32p, f32p, C.c_int32, C.POINTER(C.c_int32)]
     lib.parc_env_describe.restype = C.c_char_p
     lib.parc_env_dynamics_manifold_drops.argtypes = [vp]
     lib.parc_test_quat_op.argtypes = [C.c_int32, vp, vp, vp, C.c_int32, vp, vp]
@@ -164,7 +169,7 @@ EXPORTED_SYMBOLS = [
     "parc_env_get_motion_info", "parc_env_set_rand_reset", "parc_env_set_start_time_fraction", "parc_dof_to_rot",
     "parc_rot_to_dof", "parc_forward_kinematics", "parc_calc_motion_frame", "parc_env_get_frame_vel_tables",
     "parc_env_profile_step", "parc_env_last_dynamics_ms", "parc_env_dynamics_kernel", "parc_env_set_kernel_timing", "parc_env_get_kernel_timing", "parc_env_record_bind", "parc_env_record_frame", "parc_env_set_episode_length", "parc_td_lambda_return", "parc_normalize_record", "parc_env_bind_action", "parc_env_get_buffers", "parc_env_step_reset_graph",
-    "parc_test_quat_op", "parc_build_flags", "parc_env_set_never_done", "parc_env_dynamics_timeouts", "parc_env_dynamics_manifold_drops", "parc_env_describe",
+    "parc_test_quat_op", "parc_build_flags", "parc_env_set_never_done", "parc_env_dynamics_timeouts", "parc_env_dynamics_manifold_drops", "parc_env_describe", "parc_env_get_kernel_timing_samples", "parc_env_health_words",
     "parc_env_post_kernel",
 ]
 
@@ -172,7 +177,12 @@ EXPORTED_SYMBOLS = [
 QOP = {"mul": 0, "rotate": 1, "conj": 2, "pos": 3, "normalize3": 4, "to_axis_angle": 5, "aa_to_quat": 6, "exp_map_to_quat": 7,
        "to_exp_map": 8, "diff_angle": 9, "normalize": 10, "to_tan_norm": 11, "slerp": 12, "heading": 13, "heading_quat_inv": 14,
        "diff": 15, "rotate_2d": 16, "slerp_rr": 17}
-REQUIRED_BUILD_FLAGS = ("-fno-slp-vectorize", "-ffp-contract=off")
+# -pragma-unroll-threshold: without it the unrolled body loops of k_dynamics_wave stay rolled, its per-body register arrays become ~1 KB of
+# scratch per lane and the kernel is several times slower -- a library built without it is refused like one built with SLP
+REQUIRED_BUILD_FLAGS = ("-fno-slp-vectorize", "-ffp-contract=off", "-pragma-unroll-threshold=1048576")
+# defines of TEST-ONLY builds (__graft_entry__.BREAK_FLAGS): load() refuses a library whose build-flag string carries one unless the
+# caller opts in (PARC_ALLOW_TEST_BUILD=1, set by the one test that loads the break-flag variant)
+TEST_BUILD_MARKERS = ("-DPARC_TEST_BREAK_FLAG",)
 
 
 class ParcError(RuntimeError):

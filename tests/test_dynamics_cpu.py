@@ -456,3 +456,23 @@ def test_contact_geometry_agrees_with_the_physx_recorded_contact_flags(dyn, orac
         r = res[eps]
         assert r["all"] > 0.98 and r["feet"] > 0.94 and r["hands"] > 0.98, (eps, r)
         assert abs(r["foot_rate"] - ref[:, feet].mean()) < 0.02, (eps, r["foot_rate"], ref[:, feet].mean())
+
+
+def test_collision_set_that_does_not_fit_the_tables_is_reported(dyn):
+    """Round-3 advice: a model with more collision points than the fixed tables hold (DYN_MAXC = 48: the humanoid has 42, one more box adds 8)
+    used to be shortened silently -- a contact model that depends on the geom order.  The model builder counts what it could not place
+    (`DynModel::truncated`); parc_env_create refuses such a model with PARC_ERR_INVALID (GPU test), the humanoid reports 0."""
+    import ctypes as C
+    d, sc = dyn
+    assert d.truncated() == 0
+    cfg2 = type(sc.cfg)()
+    C.memmove(C.byref(cfg2), C.byref(sc.cfg), C.sizeof(cfg2))   # a byte copy: the nested structs are values, the pointers stay valid (sc lives on)
+    k = cfg2.dynamics.num_geoms
+    cfg2.dynamics.geom_body[k] = 2; cfg2.dynamics.geom_type[k] = 0   # a box on the head
+    for a in range(3):
+        cfg2.dynamics.geom_pos[k][a] = 0.0; cfg2.dynamics.geom_size[k][a] = 0.05
+    cfg2.dynamics.geom_density[k] = 1000.0
+    cfg2.dynamics.num_geoms = k + 1
+    from oracle.binding_dyn import DynOracle
+    d2 = DynOracle(cfg2)
+    assert d2.truncated() == 2          # 42 + 8 - 48

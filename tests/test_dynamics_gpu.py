@@ -406,7 +406,14 @@ assert env.dynamics_timeouts() == 0 and torch.isfinite(env._char_root_pos).all()
 obs, rew, done, info = env.step(env._char_dof_pos.clone())
 torch.cuda.synchronize()
 n_to = env.dynamics_timeouts()
-assert n_to >= 4, n_to                                     # 4 blocks x 4 substeps, wave 0 waits for the flag that is never published
+assert n_to >= 4, n_to                                     # every block: wave 0 waits for the flag that is never published (once a block has timed out its later waits give up at once)
+assert env._health is not None and int(env._health[0]) == n_to   # the host-mapped copy, refreshed by the launch that closed the step
+try:                                                       # ... which the NEXT step reads without a synchronisation: the run stops there
+    env.step(env._char_dof_pos.clone())
+except L.ParcError as ex:
+    assert "timed out" in str(ex)
+else:
+    raise AssertionError("step() must raise once the host-mapped health counter is non-zero")
 assert torch.isnan(env._char_root_pos).all()               # every block saw a timeout: every env is poisoned ...
 assert torch.isnan(obs).any(dim=1).all() and torch.isnan(rew).all()   # ... and so is what the learner would read
 try:
@@ -431,7 +438,7 @@ def test_flag_timeout_is_counted_and_poisons_the_state(tmp_path):
     assert os.path.exists(lib), "build it with __graft_entry__.build()"
     script = tmp_path / "breakflag.py"
     script.write_text(_BREAK_BODY.format(repo=REPO))
-    p = subprocess.run([sys.executable, str(script)], env=dict(os.environ, PARC_ENV_LIB=lib), capture_output=True, text=True, timeout=600)
+    p = subprocess.run([sys.executable, str(script)], env=dict(os.environ, PARC_ENV_LIB=lib, PARC_ALLOW_TEST_BUILD="1"), capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "BREAKFLAG_OK" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])
 
 

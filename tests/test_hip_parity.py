@@ -589,19 +589,22 @@ def test_reset_done_device_side(tmp_path):
     assert np.all(fr > 0) and np.all(fr <= 1.0) and np.any(fr < 1.0)
 
 
-def test_dynamics_kernel_matches_cpu_build(tmp_path):
-    """k_dynamics (HIP) vs the host build of the same core (oracle/dyn_oracle.cpp): one control step = 4 substeps.
+@pytest.mark.parametrize("n", [2048, 9216])
+def test_dynamics_kernel_matches_cpu_build(tmp_path, n):
+    """k_dynamics_wave (HIP; 32-env blocks at 2 048 envs, 64-env blocks at 9 216) vs the host build of the same equations
+    (oracle/dyn_oracle.cpp): one control step = 4 substeps, contact discovery + cached planes included.
     PhysX parity is unpinned; this checks that the GPU computes what the CPU build computes."""
     import torch
     from gpu_helpers import default_config, write_motion_yaml, to_np
     from helpers import CLIPS4
     from oracle.binding_dyn import DynOracle
     from parc_amd.envs.hip_parkour_env import HipParkourEnv
-    n = 2048
     cfg = default_config()
     cfg["env"]["dm"]["motion_file"] = write_motion_yaml(tmp_path, CLIPS4, [1, 1, 1, 1])
     env = HipParkourEnv(cfg, n, "cuda:0", False, seed=5, enable_dynamics=True)
     env.reset()
+    desc = env.describe()
+    assert desc["dynamics_kernel"] == "k_dynamics_wave" and desc["envs_per_block"] == ("32" if n == 2048 else "64") and desc["dev_options"] == "none"
     d = DynOracle(env._scene.cfg)
     sc = env._scene
     hf, mp, dxdy = sc.grid.terrain.hf, sc.grid.terrain.min_point, sc.grid.terrain.dxdy
@@ -626,7 +629,15 @@ def test_dynamics_kernel_matches_cpu_build(tmp_path):
             err = np.abs(to_np(getattr(env, k_e)) - st[k_o]).reshape(n, -1).max(1)
             out = err > 20 * tol
             assert np.quantile(err[~out], 0.999) <= tol, (it, k_o, np.quantile(err[~out], 0.999))
-            assert out.mean() <= 2e-3 and set_differs[out].all(), (it, k_o, out.sum(), err[out], set_differs[out])
+            # (9 216 envs: the host build's env-local coordinates -- ulp 3e-5 m at 400 m -- can also move a point across the MARGIN of a
+            # speculative plane, which the reported forces do not show: there only the number of such envs is bounded; measured 1 of 9 216 x 4)
+            assert out.mean() <= 2e-3 and (n != 2048 or set_differs[out].all()), (it, k_o, out.sum(), err[out], set_differs[out])
+            # envs on whose contact set the two builds agree: a hard cap (round-3 advice).  8 x tol at 2 048 envs (measured worst 7 x tol); at
+            # 9 216 envs the HOST build is the imprecise side -- it works in env-local coordinates of up to 400 m (ulp 3e-5 m), the kernel
+            # in the patch frame -- measured worst 14 x tol with single envs beyond: there the quantile and the outlier count above are the check
+            same = ~set_differs
+            if n == 2048:
+                assert err[same].max() <= 8 * tol, (it, k_o, err[same].max() / tol)
             if k_o == "root_pos":
                 assert err.max() < 1e-2, (it, err.max())
         fz_g = to_np(env._char_contact_forces)[:, :, 2].sum(1); fz_c = st["contact_force"][:, :, 2].sum(1)
