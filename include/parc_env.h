@@ -315,6 +315,15 @@ int parc_td_lambda_return(const float *reward, const float *next_vals, const int
 int parc_normalize_record(const float *x, const float *mean, const float *std, float clip, float *norm_out, float *copy_out,
                           int64_t n, int32_t dim, void *stream);
 
+/* Minibatch gather of the experience buffer (experience_buffer.py:81-89: `{k: v[idx] for k, v in flat_buffers}`, one indexing kernel per
+ * buffer in the reference).  ONE launch copies, for every sampled row r < n, row (idx[r] mod count) of each of the
+ * num_buffers flat buffers into row r of its contiguous minibatch tensor: src[b] / dst[b] are device pointers, row_bytes[b] the size of one
+ * row of buffer b in bytes (any element type: the copy is byte-exact, i.e. bit-identical to index_select).  idx: device int64.  Rows of
+ * at least 64 bytes are moved by a wavefront each (16-byte lanes where the row is 16-byte aligned), narrower ones by one thread per row. */
+#define PARC_MAX_GATHER_BUFFERS 16
+int parc_gather_rows(int32_t num_buffers, const void *const *src_dev, void *const *dst_dev, const int64_t *row_bytes, const int64_t *idx_dev,
+                     int64_t n, int64_t count, void *stream);
+
 /* Recorder (IGParkourEnv.write_agent_states, ig_parkour_env.py:759-796; driven by dm_motion_recorder.py:52-121).
  * The reference appends one row per recording env to Python lists every step; here the rows go to device ring buffers
  * owned by the caller:

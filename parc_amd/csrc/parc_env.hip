@@ -2182,6 +2182,75 @@ extern "C" int parc_normalize_record(const float *x, const float *mean, const fl
 }
 
 // Recorder: one 128-thread block per env appends that env's row (see include/parc_env.h).
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Minibatch gather (experience_buffer.py:81-89): block = 256 sampled rows.  Narrow buffers (a scalar or a few values per sample: reward,
+// done, advantage ...): thread t copies row t.  Wide buffers (observations 5 248 B, actions 112 B): the block's four waves walk its 256 rows,
+// a wavefront per row, 16 bytes per lane where source and destination rows are 16-byte aligned (else 4 / 1 bytes).  HBM-bound: 2 x the
+// minibatch's bytes; bit-identical to index_select by construction (a byte copy).
+struct GatherArgs {
+    const char *src[PARC_MAX_GATHER_BUFFERS];
+    char *dst[PARC_MAX_GATHER_BUFFERS];
+    long long row_bytes[PARC_MAX_GATHER_BUFFERS];
+    int nb;
+};
+
+__global__ __launch_bounds__(256) void k_gather_rows(const GatherArgs A, const long long *__restrict__ idx, long long n, long long count) {
+    __shared__ long long s_row[256];
+    const long long r0 = (long long)blockIdx.x * 256;
+    const int t = threadIdx.x;
+    long long mine = -1;
+    if (r0 + t < n) {
+        long long i = idx[r0 + t] % count;   // torch.remainder(idx, sample_count): idx >= 0
+        if (i < 0) i += count;
+        mine = i;
+    }
+    s_row[t] = mine;
+    __syncthreads();
+    const int lane = t & 63, w = t >> 6;
+    for (int b = 0; b < A.nb; ++b) {
+        const long long rb = A.row_bytes[b];
+        if (rb < 64) { // narrow: one thread per row
+            if (mine >= 0) {
+                const char *s = A.src[b] + mine * rb;
+                char *d = A.dst[b] + (r0 + t) * rb;
+                if ((rb & 3) == 0 && ((((uintptr_t)s) | ((uintptr_t)d)) & 3) == 0) for (long long k = 0; k < rb; k += 4) *(int *)(d + k) = *(const int *)(s + k);
+                else for (long long k = 0; k < rb; ++k) d[k] = s[k];
+            }
+        } else {       // wide: one wavefront per row, rows w, w + 4, ... of the block
+            for (int q = w; q < 256; q += 4) {
+                const long long i = s_row[q];
+                if (i < 0) break; // rows past n (only at the end of the last block)
+                const char *s = A.src[b] + i * rb;
+                char *d = A.dst[b] + (r0 + q) * rb;
+                if ((rb & 15) == 0 && ((((uintptr_t)s) | ((uintptr_t)d)) & 15) == 0) {
+                    for (long long k = 16ll * lane; k < rb; k += 1024) *(float4 *)(d + k) = *(const float4 *)(s + k);
+                } else if ((rb & 3) == 0 && ((((uintptr_t)s) | ((uintptr_t)d)) & 3) == 0) {
+                    for (long long k = 4ll * lane; k < rb; k += 256) *(int *)(d + k) = *(const int *)(s + k);
+                } else {
+                    for (long long k = lane; k < rb; k += 64) d[k] = s[k];
+                }
+            }
+        }
+    }
+}
+
+extern "C" int parc_gather_rows(int32_t num_buffers, const void *const *src_dev, void *const *dst_dev, const int64_t *row_bytes, const int64_t *idx_dev,
+                                int64_t n, int64_t count, void *stream) {
+    if (num_buffers < 1 || num_buffers > PARC_MAX_GATHER_BUFFERS) return fail(PARC_ERR_INVALID, "parc_gather_rows: 1..16 buffers");
+    if (!src_dev || !dst_dev || !row_bytes || !idx_dev || n < 0 || count < 1) return fail(PARC_ERR_INVALID, "parc_gather_rows: bad argument");
+    if (n == 0) return PARC_OK;
+    GatherArgs A;
+    memset(&A, 0, sizeof(A));
+    A.nb = num_buffers;
+    for (int b = 0; b < num_buffers; ++b) {
+        if (!src_dev[b] || !dst_dev[b] || row_bytes[b] < 1) return fail(PARC_ERR_INVALID, "parc_gather_rows: null buffer or empty row");
+        A.src[b] = (const char *)src_dev[b]; A.dst[b] = (char *)dst_dev[b]; A.row_bytes[b] = row_bytes[b];
+    }
+    hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, A, (const long long *)idx_dev, (long long)n, (long long)count);
+    HIPCHK(hipGetLastError());
+    return PARC_OK;
+}
+
 __global__ __launch_bounds__(128) void k_record(const DevTables *__restrict__ T, ParcEnvBuffers buf, int N, int B, int D, int obs_dim, float *frames,
                                                 float *obs_out, int cap, int *count, unsigned char *writing, int *n_writing, int use_ref) {
     const int e = blockIdx.x, tid = threadIdx.x;

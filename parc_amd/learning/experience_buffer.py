@@ -57,14 +57,32 @@ class ExperienceBuffer:
         buf[:] = data
 
     def sample(self, n):
-        idx = self._sample_rand_idx(n)
-        return {k: v[idx] for k, v in self._flat_buffers.items()}
+        """experience_buffer.py:81-89.  On the GPU the rows of ALL buffers are gathered by one HIP launch (parc_gather_rows: byte-exact,
+        i.e. bit-identical to the per-buffer indexing kernels it replaces); CPU tensors (the gloo tests) keep torch's indexing."""
+        idx = self._sample_rand_idx(n, wrap=False)
+        count = self.get_sample_count()
+        bufs = self._flat_buffers
+        if len(bufs) == 0 or not all(v.is_cuda and v.is_contiguous() for v in bufs.values()) or len(bufs) > 16:
+            idx = torch.remainder(idx, count)
+            return {k: v[idx] for k, v in bufs.items()}
+        import ctypes as C
+        from parc_amd import lib as L
+        lib = L.load()
+        names = list(bufs)
+        out = {k: torch.empty((n,) + tuple(bufs[k].shape[1:]), dtype=bufs[k].dtype, device=bufs[k].device) for k in names}
+        nb = len(names)
+        src = (C.c_void_p * nb)(*[bufs[k].data_ptr() for k in names])
+        dst = (C.c_void_p * nb)(*[out[k].data_ptr() for k in names])
+        rb = (C.c_int64 * nb)(*[(bufs[k][0].numel() * bufs[k].element_size()) for k in names])
+        idx = idx.contiguous()
+        L.check(lib.parc_gather_rows(nb, src, dst, rb, idx.data_ptr(), int(n), int(count), torch.cuda.current_stream().cuda_stream))
+        return out
 
     def _reset_sample_buf(self):
         self._sample_buf[:] = torch.randperm(self._buffer_length * self._batch_size, device=self._device, dtype=torch.long)
         self._sample_buf_head = 0
 
-    def _sample_rand_idx(self, n):
+    def _sample_rand_idx(self, n, wrap=True):
         total = self._sample_buf.shape[0]
         assert n <= total
         if self._sample_buf_head + n <= total:
@@ -76,4 +94,4 @@ class ExperienceBuffer:
             self._reset_sample_buf()
             idx = torch.cat([head, self._sample_buf[:rem]], dim=0)
             self._sample_buf_head = rem
-        return torch.remainder(idx, self.get_sample_count())
+        return torch.remainder(idx, self.get_sample_count()) if wrap else idx   # (the gather kernel takes the remainder itself)

@@ -149,6 +149,7 @@ def load():
     lib.parc_env_set_never_done.argtypes = [vp, C.c_int32]
     lib.parc_env_dynamics_timeouts.argtypes = [vp]
     lib.parc_env_describe.argtypes = [vp]
+    lib.parc_gather_rows.argtypes = [C.c_int32, C.POINTER(vp), C.POINTER(vp), i64p, vp, C.c_int64, C.c_int64, vp]
     lib.parc_env_health_words.argtypes = [vp]
     lib.parc_env_health_words.restype = C.POINTER(C.c_uint32)
     lib.parc_env_get_kernel_timing_samples.argtypes = [vp, f32p, f32p, f32p, C.c_int32, C.POINTER(C.c_int32)]
@@ -169,7 +170,7 @@ EXPORTED_SYMBOLS = [
     "parc_env_get_motion_info", "parc_env_set_rand_reset", "parc_env_set_start_time_fraction", "parc_dof_to_rot",
     "parc_rot_to_dof", "parc_forward_kinematics", "parc_calc_motion_frame", "parc_env_get_frame_vel_tables",
     "parc_env_profile_step", "parc_env_last_dynamics_ms", "parc_env_dynamics_kernel", "parc_env_set_kernel_timing", "parc_env_get_kernel_timing", "parc_env_record_bind", "parc_env_record_frame", "parc_env_set_episode_length", "parc_td_lambda_return", "parc_normalize_record", "parc_env_bind_action", "parc_env_get_buffers", "parc_env_step_reset_graph",
-    "parc_test_quat_op", "parc_build_flags", "parc_env_set_never_done", "parc_env_dynamics_timeouts", "parc_env_dynamics_manifold_drops", "parc_env_describe", "parc_env_get_kernel_timing_samples", "parc_env_health_words",
+    "parc_test_quat_op", "parc_build_flags", "parc_env_set_never_done", "parc_env_dynamics_timeouts", "parc_env_dynamics_manifold_drops", "parc_env_describe", "parc_env_get_kernel_timing_samples", "parc_env_health_words", "parc_gather_rows",
     "parc_env_post_kernel",
 ]
 

@@ -289,3 +289,42 @@ def test_curriculum_launch_variants_are_bit_identical(tmp_path, monkeypatch):
     for other in envs[1:]:
         assert torch.equal(envs[0]._motion_ids, other._motion_ids) and torch.equal(envs[0]._timestep_buf, other._timestep_buf)
         assert torch.equal(envs[0]._obs_buf, other._obs_buf)
+
+
+def test_minibatch_gather_is_bit_identical_to_indexing():
+    """experience_buffer.py:81-89: `sample(n)` gathers the sampled rows of every buffer with ONE HIP launch
+    (parc_gather_rows) instead of one indexing kernel per buffer; byte-exact against torch indexing for float / int / bool buffers, wide and
+    narrow rows, rows that are not 16-byte aligned, a ragged last block, the wrap-around of the shuffled index buffer and a partly filled
+    buffer (the remainder by the sample count)."""
+    import torch
+    from parc_amd.learning.experience_buffer import ExperienceBuffer
+    T, N = 8, 1000
+    dev = "cuda:0"
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    eb = ExperienceBuffer(T, N, dev)
+    bufs = {"obs": torch.randn(T, N, 1312, device=dev, generator=g), "action": torch.randn(T, N, 28, device=dev, generator=g),
+            "odd": torch.randn(T, N, 17, device=dev, generator=g),        # 68-byte rows: wide, 4-byte path
+            "reward": torch.randn(T, N, device=dev, generator=g), "done": torch.randint(0, 4, (T, N), device=dev, generator=g, dtype=torch.int32),
+            "mask": torch.rand(T, N, 1, device=dev, generator=g) < 0.5, "ep": torch.randint(0, 1 << 40, (T, N), device=dev, generator=g, dtype=torch.int64),
+            "bytes3": torch.randint(0, 255, (T, N, 3), device=dev, generator=g, dtype=torch.uint8)}
+    for k, v in bufs.items():
+        eb.add_buffer(k, v)
+    for filled in (T, 3):            # full buffer; 3 of 8 steps recorded (indices wrap by the sample count)
+        eb.clear()
+        for _ in range(filled):
+            eb.inc()
+        count = eb.get_sample_count()
+        assert count == filled * N
+        for n in (1, 255, 256, 700, 3001, 7999):    # 7999 + 3001 crosses the end of the shuffled index buffer
+            head = eb._sample_buf_head
+            perm = eb._sample_buf.clone()
+            out = eb.sample(n)
+            torch.cuda.synchronize()
+            if head + n <= perm.shape[0]:
+                idx = torch.remainder(perm[head:head + n], count)
+                for k, v in bufs.items():
+                    ref = v.view(T * N, *v.shape[2:])[idx]
+                    assert out[k].dtype == v.dtype and out[k].shape == ref.shape and torch.equal(out[k], ref), (k, n, filled)
+            else:   # the buffer was reshuffled inside the call: every row must still be A row of the filled part, and finite
+                flat = bufs["ep"].view(-1)[:count]
+                assert torch.isin(out["ep"], flat).all()
