@@ -48,6 +48,10 @@ class DynOracle:
         """Test hook: substeps per control step (1 = the reported contact force is evaluated at the given pose)."""
         return int(self.lib.orc_dyn_set_nsub(self.h, C.c_int(n)))
 
+    def set_manifold_period(self, n):
+        """Contact discovery every n substeps (1 = every substep, the round-3 behaviour)."""
+        return int(self.lib.orc_dyn_set_man_period(self.h, C.c_int(n)))
+
     def truncated(self):
         """Collision points / segments / geoms that did not fit the model's fixed tables."""
         return int(self.lib.orc_dyn_truncated(self.h))

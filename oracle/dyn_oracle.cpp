@@ -63,6 +63,12 @@ void orc_dyn_inflate(void *m, float eps) {
 int orc_dyn_set_nsub(void *m, int n) { DynModel *M = (DynModel *)m; const int old = M->nsub; M->nsub = n; return old; }
 // collision points / segments / geoms that did not fit the model's fixed tables (parc_env_create refuses a model with any)
 int orc_dyn_truncated(void *m) { return ((DynModel *)m)->truncated; }
+// contact discovery every n substeps (1 = every substep: the round-3 behaviour, the cached planes then never act); returns the old value
+int orc_dyn_set_man_period(void *m, int n) {
+    DynModel *M = (DynModel *)m; const int old = M->man_period;
+    M->man_period = n < 1 ? 1 : n; M->spec_tv = 1.5f * (float)(M->man_period - 1) * M->dt;
+    return old;
+}
 int orc_dyn_get_nseg(void *m) { return ((DynModel *)m)->nseg; }
 // counterfactual for the tests: drop the collision segments (points only, the round-2 contact geometry); returns the old count
 int orc_dyn_set_nseg(void *m, int n) { DynModel *M = (DynModel *)m; const int old = M->nseg; M->nseg = n; return old; }

@@ -476,3 +476,45 @@ def test_collision_set_that_does_not_fit_the_tables_is_reported(dyn):
     from oracle.binding_dyn import DynOracle
     d2 = DynOracle(cfg2)
     assert d2.truncated() == 2          # 42 + 8 - 48
+
+
+def test_physx_recorded_transitions_one_step_and_closed_loop(dyn, oracle, orc_char):
+    """The PhysX-anchored check of the integrator that needs no policy (round-3 verdict, item 6; tests/physx_transitions.py has the method).
+    From every recorded state of `dec2024_teaser_717_1_opt_dm.pkl` (pose from the frames, velocities from the recorded observation stream) the PD
+    targets are the ones that put THIS simulator's joints on the recorded next joint angles; what is compared with PhysX is what no target can
+    buy: the motion of the unactuated floating base and the set of touching bodies.
+      * one step (141 transitions): the root lands within 6.6 mm (median) of where PhysX put it -- closer than the constant-velocity
+        extrapolation of the recorded state (7.7 mm) --, contact flags agree on 98 % of the (frame, body) pairs, feet 90 %;
+      * closed loop, 10 control steps on the SIMULATED state (47 starts): root height within 1.1 cm (median; free fall would be 54 cm), root position
+        5 cm, root rotation 0.13 rad, feet flags 84 %, foot contact rate 0.48 vs 0.57 recorded.  The open-loop replay of the same file
+        (tests/test_dynamics_gpu.py) loses 9.7 cm of height and agrees on 72 % of the feet flags: it fails these thresholds;
+      * the check discriminates: without friction the root turns 0.43 rad and the feet agreement drops to 68 %; with contacts 100 x softer the
+        root sinks 25 cm -- both counterfactuals fail the same thresholds (asserted)."""
+    from conftest import golden
+    from oracle.binding_dyn import DynOracle
+    from physx_transitions import closed_loop, load, one_step
+    d0, sc = dyn
+    R = load(oracle, orc_char, golden("char_model"))
+    r = one_step(DynOracle(sc.cfg), oracle, R)
+    assert np.median(r["e_pos"]) < 0.009 and np.median(r["e_pos"]) < np.median(r["e_cv"]) and r["e_pos"].max() < 0.03
+    assert np.median(r["e_z"]) < 0.006 and np.median(r["e_rot"]) < 0.015
+    assert np.median(r["e_vel"]) < np.median(np.linalg.norm(R["root_vel"][1:] - R["root_vel"][:-1], axis=1))     # beats "the velocity does not change"
+    assert r["agree_all"] > 0.97 and r["agree_feet"] > 0.88 and abs(r["foot_rate_sim"] - r["foot_rate_ref"]) < 0.10
+    assert r["false_neg"] < 0.02       # a body PhysX reports in contact at both ends of the step and this simulator leaves in the air
+
+    def passes(m):
+        return (m["e_z_med"] < 0.03 and m["e_pos_med"] < 0.08 and m["e_rot_med"] < 0.20 and m["agree_all"] > 0.95 and m["agree_feet"] > 0.78
+                and abs(m["foot_rate_sim"] - m["foot_rate_ref"]) < 0.15)
+    cl = closed_loop(DynOracle(sc.cfg), oracle, R)
+    print("closed loop, h = 10:", cl[-1])
+    assert passes(cl[-1]), cl[-1]
+    assert all(m["e_z_med"] < 0.03 for m in cl)                       # the height never drifts on the way
+    # the open-loop replay's own numbers (0.097 m height error, 72 % feet flags) would not pass:
+    assert not passes(dict(cl[-1], e_z_med=0.097, agree_feet=0.72))
+    # counterfactual models must fail
+    for kw in (dict(mu=0.0), dict(kn=5e2, dn=5.0, dtang=3e2)):
+        d = DynOracle(sc.cfg)
+        c = d.get_contact(); c.update(kw)
+        d.set_contact(c["kn"], c["dn"], c["dtang"], c["mu"])
+        m = closed_loop(d, oracle, R)[-1]
+        assert not passes(m), (kw, m)
