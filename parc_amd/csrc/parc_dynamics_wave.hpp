@@ -66,8 +66,8 @@ struct WaveTables {
     int body[1 + WV_MAXLIMB][WV_MAXLEN];
     int par_slot[1 + WV_MAXLIMB];          // attach slot of the trunk body a limb hangs off
     int early[1 + WV_MAXLIMB];             // limb hangs off a non-root trunk body: finished before the trunk's upper part starts
-    int ep_trunk_wave, ep_head_wave;       // epilogue: which waves (>= 1) form the prep-record quaternions of the trunk joints / the heading terms of
-                                           // the root from what wave 0 hands over (-1: wave 0 does it itself)
+    int ep_trunk_wave[WV_MAXLEN], ep_head_wave; // epilogue: which wave (>= 1) forms the prep-record quaternion of trunk position k / the heading terms
+                                                // of the root from what wave 0 hands over (-1: wave 0 does it itself)
     int helper;                            // wave (>= 1) of an early limb: idle in part B, it prepares own inertia + contacts of trunk bodies; -1 if none
     int prep[WV_MAXLEN];                   // per trunk position: 1 = own inertia + contacts prepared by another wave (rec_wave), handed over as a record
     int rec_wave[WV_MAXLEN];               // that wave (>= 1), or -1: wave 0 does the body itself.  Position 0 (the root body) is prepared AFTER the
@@ -164,8 +164,15 @@ inline bool build_wave_tables(const DynModel &M, const CoopTables &C, WaveTables
     for (int k = 0; k < W.len[0]; ++k) W.prep[k] = W.rec_wave[k] >= 1 ? 1 : 0;
     // epilogue shares: wave 0 is the last one out of the substep loop, so the transcendental-heavy prep-record work on ITS state (heading
     // terms of the root, dof -> quat of the trunk joints) goes to two other waves, which are through their own stores by then
+    // (one joint per wave: a spherical joint's dof -> quat is ~700 instructions that only THIS wave executes -- cold in the instruction
+    // cache, 9 k cycles --; two of them on one wave made that wave the last one out, measured)
     W.ep_head_wave = W.helper;
-    W.ep_trunk_wave = W.helper >= 1 && root_limb >= 1 ? root_limb : W.helper;
+    {
+        int cand[WV_MAXLIMB], nc = 0;
+        for (int c = 2; c < C.nchain; ++c) if (c - 1 != W.helper) cand[nc++] = c - 1;   // the waves that carry neither wave 0's nor the helper's share
+        for (int k = 0; k < WV_MAXLEN; ++k) W.ep_trunk_wave[k] = W.helper;
+        for (int k = 1, at = 0; k < W.len[0] && nc > 0 && W.helper >= 1; ++k, ++at) W.ep_trunk_wave[k] = cand[at % nc];
+    }
     {   // LDS shares of the plane lists: two slots each, the rest in proportion to the candidates a wave discovers
         int cand[WV_MAXLIMB] = {0, 0, 0, 0}, tot = 0, used = 0;
         for (int w = 0; w < WV_MAXLIMB; ++w) {
@@ -880,7 +887,9 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
 #endif
         // every lane wrote its env's slot of the record: the wave's LDS stores complete in order, the fence waits for them (one
         // s_waitcnt for the whole wave), then lane 0 raises the flag
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        // (the fences of publish / await order LDS traffic only -- every hand-off record lives in LDS --: the "local" form does not wait for
+        // the wave's global stores to drain, which in the epilogue are ~100 row-strided stores per lane, 18 k cycles)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
         if (lane == 0) __hip_atomic_store(&s_flag[f], sub + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
     auto await = [&](int f, int sub) __attribute__((always_inline)) {
@@ -898,7 +907,7 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
             }
             __builtin_amdgcn_s_sleep(2);
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
     };
     auto trunk_kinematics = [&](int sub) __attribute__((always_inline)) { // wave 0
         s_rootp[0] = rp.x; s_rootp[64] = rp.y; s_rootp[128] = rp.z;
@@ -1188,13 +1197,16 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
         if (k < llen) wv_store_joint(M, W, W.body[lc][k], limb[k], odp, odv, ocf, pr);
         if (k < tlen) wv_store_joint(M, W, W.body[0][k], trunk[k], odp, odv, ocf, hand ? nullptr : pr);
     }
-    if (hand && (w == W.ep_trunk_wave || w == W.ep_head_wave)) {
+    bool mine_ep = w == W.ep_head_wave;
+    PARC_UNROLL
+    for (int k = 1; k < WV_MAXLEN; ++k) mine_ep = mine_ep || (k < W.len[0] && W.ep_trunk_wave[k] == w);
+    if (hand && mine_ep) {
         await(WV_F_HAND, 0);
-        if (w == W.ep_trunk_wave) {
+        {
             PARC_UNROLL
-            for (int k = 0; k < WV_MAXLEN; ++k) {
+            for (int k = 1; k < WV_MAXLEN; ++k) {
                 const int b = W.body[0][k];
-                if (k < W.len[0] && b != 0) {
+                if (k < W.len[0] && W.ep_trunk_wave[k] == w) {
                     const int jt = W.c[b].jtype;
                     if (jt == DJ_SPHERICAL) pr[b] = parc::exp_map_to_quat(parc::mk3(s_hand[(3 * k) * 64], s_hand[(3 * k + 1) * 64], s_hand[(3 * k + 2) * 64]));
                     else if (jt == DJ_HINGE) pr[b] = parc::axis_angle_to_quat(parc::mk3(W.c[b].axis[0], W.c[b].axis[1], W.c[b].axis[2]), s_hand[(3 * k) * 64]);
