@@ -818,11 +818,6 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
     man.lds = smem + WV_OFF_MAN + W.man_base[w] * (8 * 64) + lane; man.cap = W.man_cap[w];
     man.glb = man_g + ((size_t)blockIdx.x * WV_MAXLIMB + w) * (WV_MAN_OVF * 8 * 64) + lane;
     man.cur = 0; man.cnt = 0ull;
-    PARC_UNROLL
-    for (int k = 0; k < WV_MAXLEN; ++k) {
-        if (k < llen) wv_load_joint(M, W, W.body[lc][k], limb[k], dp, dv, ac);
-        if (k < tlen) wv_load_joint(M, W, W.body[0][k], trunk[k], dp, dv, ac);
-    }
     const v3 rp_buf = mk(buf.char_root_pos[3 * ec], buf.char_root_pos[3 * ec + 1], buf.char_root_pos[3 * ec + 2]);
     q4 rq; rq.x = buf.char_root_rot[4 * ec]; rq.y = buf.char_root_rot[4 * ec + 1]; rq.z = buf.char_root_rot[4 * ec + 2]; rq.w = buf.char_root_rot[4 * ec + 3];
     rq = qnormalize(rq);
@@ -862,6 +857,13 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
         for (int it = 0; it < NP; ++it) {
             const int i = w + 4 * it;
             hv[it] = i < DYN_PATCH * DYN_PATCH ? hf_at(T, X.pox + i / DYN_PATCH, X.poy + i % DYN_PATCH) : 0.f;
+        }
+        // the joint state (loads, then two exp maps per spherical joint) in the shadow of the patch loads, which sit at the end of the
+        // prologue's only dependent chain of global loads (root position + env origin -> cell -> heights)
+        PARC_UNROLL
+        for (int k = 0; k < WV_MAXLEN; ++k) {
+            if (k < llen) wv_load_joint(M, W, W.body[lc][k], limb[k], dp, dv, ac);
+            if (k < tlen) wv_load_joint(M, W, W.body[0][k], trunk[k], dp, dv, ac);
         }
         PARC_UNROLL
         for (int it = 0; it < NP; ++it) {

@@ -14,7 +14,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R
 echo "stats pass done"
 pmc() { # <dir> <counters> <bench args...>
   local d=$1 c=$2; shift 2
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$d -- python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline "$@" > /dev/null 2> $OUT/$d.log
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$d -- python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --kernel-sample-steps 0 "$@" > /dev/null 2> $OUT/$d.log
   echo "$d done"
 }
 pmc fetch FETCH_SIZE
