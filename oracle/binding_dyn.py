@@ -52,6 +52,10 @@ class DynOracle:
         """Contact discovery every n substeps (1 = every substep, the round-3 behaviour)."""
         return int(self.lib.orc_dyn_set_man_period(self.h, C.c_int(n)))
 
+    def set_speculative_margin(self, m0, tv, mx):
+        """Test hook: margin of the contact discovery = min(m0 + tv * approach speed, mx); (0, 0, 0) = only touching candidates become planes."""
+        self.lib.orc_dyn_set_spec(self.h, C.c_float(m0), C.c_float(tv), C.c_float(mx))
+
     def truncated(self):
         """Collision points / segments / geoms that did not fit the model's fixed tables."""
         return int(self.lib.orc_dyn_truncated(self.h))

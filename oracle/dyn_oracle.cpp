@@ -69,6 +69,8 @@ int orc_dyn_set_man_period(void *m, int n) {
     M->man_period = n < 1 ? 1 : n; M->spec_tv = 1.5f * (float)(M->man_period - 1) * M->dt;
     return old;
 }
+// test hook: the speculative margin of the contact discovery, margin = min(m0 + tv * approach speed, mx)
+void orc_dyn_set_spec(void *m, float m0, float tv, float mx) { DynModel *M = (DynModel *)m; M->spec_m0 = m0; M->spec_tv = tv; M->spec_max = mx; }
 int orc_dyn_get_nseg(void *m) { return ((DynModel *)m)->nseg; }
 // counterfactual for the tests: drop the collision segments (points only, the round-2 contact geometry); returns the old count
 int orc_dyn_set_nseg(void *m, int n) { DynModel *M = (DynModel *)m; const int old = M->nseg; M->nseg = n; return old; }

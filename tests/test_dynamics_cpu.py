@@ -518,3 +518,64 @@ def test_physx_recorded_transitions_one_step_and_closed_loop(dyn, oracle, orc_ch
         d.set_contact(c["kn"], c["dn"], c["dtang"], c["mu"])
         m = closed_loop(d, oracle, R)[-1]
         assert not passes(m), (kw, m)
+
+
+def test_contact_manifold_speculative_planes_and_cached_planes(dyn):
+    """The contact manifold of round 4 (parc_dynamics.hpp): contacts are discovered in substep 0 of a control step and kept as planes, every
+    substep re-evaluates the cached planes; discovery also keeps SPECULATIVE planes (pen > -margin, margin = min(0.02 + 0.0375 s x approach speed,
+    0.08 m)).  On single rigid bodies built through the same C structs:
+      * a 5 cm sphere coming down at 2 m/s that starts a control step 2.5 cm above the ground (it arrives in the second substep): with the margin it
+        is stopped like under discovery in every substep (period 1) -- deepest penetration within 2 mm --; WITHOUT the margin (counterfactual) the
+        cached list is empty for the rest of the control step and the sphere is 2 x deeper in the ground before anything pushes back;
+      * on flat ground the planes are exact: period 4 and period 1 give the same trajectory sample for sample;
+      * a plane outlives its cell until the next discovery (the documented price): a box pushed off a ledge at 1 m/s is carried at most one
+        control step's travel further than under period 1, then falls the same way."""
+    d, sc = dyn
+    flat = np.zeros((64, 64), np.float32)
+    ball = lambda: _single_body(sc, 1, (0.0, 0.0, 0.0), (0, 0, 0), (0.05, 0, 0), density=2000.0)
+
+    def drop(o, steps=6):
+        st = _rigid_state(1, (0.1, 0.1, 0.05 + 0.025))       # lowest point 2.5 cm above the ground at the start of the control step
+        st["root_vel"][0, 2] = -2.0
+        deepest = 0.0
+        for _ in range(steps):
+            o.step(flat, MINP, DX, st, np.zeros((1, 0), np.float32), np.zeros((1, 3), np.float32))
+            deepest = max(deepest, 0.05 - st["root_pos"][0, 2])
+        return deepest, st
+    o4 = ball()
+    o1 = ball(); o1.set_manifold_period(1)
+    o0 = ball(); o0.set_speculative_margin(0.0, 0.0, 0.0)
+    p4, s4 = drop(o4); p1, s1 = drop(o1); p0, _ = drop(o0)
+    assert 0.0 < p1 < 0.03 and abs(p4 - p1) < 0.002, (p4, p1)          # caught by the plane it was about to hit
+    assert p0 > 2.0 * p1 and p0 > p4 + 0.01, (p0, p4, p1)              # counterfactual: no margin -> the touch-down is seen a control step late
+    # on flat ground the cached planes are exact (normal +z, the column top): period 4 and period 1 produce the SAME trajectory, sample for sample
+    # (a light single body does not come to rest under this penalty law -- it chatters by 0.3 mm in a five-step cycle, under either period)
+    traj = []
+    for o in (ball(), o1):
+        st = _rigid_state(1, (0.1, 0.1, 0.05))
+        zs = []
+        for _ in range(60):
+            o.step(flat, MINP, DX, st, np.zeros((1, 0), np.float32), np.zeros((1, 3), np.float32))
+            zs.append((float(st["root_pos"][0, 2]), float(st["contact_force"][0, 0, 2])))
+        traj.append(np.array(zs))
+    assert np.abs(traj[0] - traj[1]).max() < 1e-6, np.abs(traj[0] - traj[1]).max()
+    assert 0.0490 < traj[0][:, 0].min() and traj[0][:, 0].max() < 0.0500          # it stays within a millimetre of the surface
+    # ledge: a foot-sized box slides off a platform at 1 m/s
+    a, b, c = 0.0885, 0.045, 0.0275
+    hf = _platform(1.0)       # platform on x > X_EDGE, pit on x < X_EDGE
+
+    def slide(period):
+        o = _single_body(sc, 0, (0.0, 0.0, 0.0), (0, 0, 0), (a, b, c), density=1141.0)
+        o.set_manifold_period(period)
+        o.set_contact(5.0e4, 5.0e2, 3.0e4, 0.0)          # frictionless: it keeps its speed
+        st = _rigid_state(1, (X_EDGE + 0.30, 0.0, 1.0 + c - 0.0005))
+        st["root_vel"][0, 0] = -1.0
+        zs = []
+        for _ in range(24):
+            o.step(hf, MINP, DX, st, np.zeros((1, 0), np.float32), np.zeros((1, 3), np.float32))
+            zs.append(float(st["root_pos"][0, 2]))
+        return np.array(zs)
+    z4, z1 = slide(4), slide(1)
+    left4, left1 = int(np.argmax(z4 < 1.0)), int(np.argmax(z1 < 1.0))       # first control step at which the box centre is below the platform top
+    assert left1 > 5 and 0 <= left4 - left1 <= 1, (left4, left1)           # carried at most one control step longer
+    assert abs(z4[-1] - z1[-1]) < 0.25 * abs(1.0 - z1[-1]) + 0.02, (z4[-1], z1[-1])    # then it falls the same way
