@@ -253,12 +253,8 @@ def torch_path_baseline(env, seconds, st, oracle, orc_lib):
     rv, rav, dv = (oracle.mlib_array(orc_lib, "frame_root_vel", (F, 3)), oracle.mlib_array(orc_lib, "frame_root_ang_vel", (F, 3)),
                    oracle.mlib_array(orc_lib, "frame_dof_vel", (F, 28)))
     nf = np.array([c.num_frames for c in clips], np.int64)
-    tables = dict(frame_root_pos=np.concatenate([c.root_pos for c in clips]), frame_root_rot=np.concatenate([c.root_rot for c in clips]),
-                  frame_joint_rot=np.concatenate([c.joint_rot for c in clips]), frame_root_vel=rv, frame_root_ang_vel=rav, frame_dof_vel=dv,
-                  frame_contacts=np.concatenate([c.contacts if c.contacts is not None else np.zeros((c.num_frames, 15), np.float32) for c in clips]),
-                  motion_num_frames=nf, motion_lengths=np.array([(c.num_frames - 1) / c.fps for c in clips], np.float32),
-                  motion_loop_modes=np.array([c.loop_mode for c in clips], np.int64), motion_start_idx=np.concatenate([[0], np.cumsum(nf)[:-1]]),
-                  motion_root_pos_delta=np.stack([np.append(c.root_pos[-1, :2] - c.root_pos[0, :2], 0.0) for c in clips]).astype(np.float32))
+    tables = tp.make_tables([dict(root_pos=c.root_pos, root_rot=c.root_rot, joint_rot=c.joint_rot, contacts=c.contacts, fps=c.fps, loop_mode=c.loop_mode) for c in clips],
+                            rv, rav, dv)
     lib = tp.MotionLib(tables)
     cores = max(1, min(os.cpu_count() or 1, 64))
     torch.set_num_threads(cores)
@@ -272,10 +268,37 @@ def torch_path_baseline(env, seconds, st, oracle, orc_lib):
         while steps < 2 or (time.time() - t0 < seconds and steps < 1000):
             tp.step_path(cm, lib, ids, times + steps / 30.0, crp, crr, cdof, 1.0 / 30.0); steps += 1
         dt = time.time() - t0
-    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} x {n} envs: PyTorch-CPU op sequence of the reference's motion_lib.calc_motion_frame (7 samples per env) + kin_char_model "
-                      "dof_to_rot / rot_to_dof / forward_kinematics (character, reference, 6 targets), torch.set_num_threads(cores); no terrain rays, "
-                      "observation assembly or reward"}
+    out = {"value": n * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+           "sample": f"{steps} x {n} envs: PyTorch-CPU op sequence of the reference's motion_lib.calc_motion_frame (7 samples per env) + kin_char_model "
+                     "dof_to_rot / rot_to_dof / forward_kinematics (character, reference, 6 targets), torch.set_num_threads(cores); no terrain rays, "
+                     "observation assembly or reward"}
+    # the WHOLE kinematic step as the reference issues it (oracle/torch_path.py::KinematicStep: + height rays, observation, reward, done;
+    # pinned against the reference's own _post_physics_step outputs by tests/test_oracle_golden.py): BASELINE.md section 2's measurement
+    # (30.9 k env-steps/s for the reference itself on 8 cores at 65 536 envs), repeated on this box's cores
+    c = sc.cfg
+    B = c.model.num_bodies
+    ks = tp.KinematicStep(cm, lib, tp.Terrain(sc.grid.terrain.hf, sc.grid.terrain.min_point, sc.grid.terrain.dxdy),
+                          dict(key_body_ids=sc.key_body_ids, tar_obs_steps=[c.tar_obs_steps[i] for i in range(c.num_tar_obs_steps)], ray_points=sc.ray_points,
+                               env_offsets=sc.env_offsets, motion_offsets=sc.grid.motion_offsets, timestep=c.control_dt, episode_length=c.episode_length,
+                               min_obs_h=c.min_obs_h, max_obs_h=c.max_obs_h, reward_weights=[c.pose_w, c.vel_w, c.root_pos_w, c.root_vel_w, c.key_pos_w],
+                               joint_err_w=sc.joint_err_w, dof_err_w=sc.dof_err_w, contact_weights=[c.contact_weights[b] for b in range(B)],
+                               pose_termination_dist=[c.pose_termination_dist[j] for j in range(B - 1)],
+                               root_pos_termination_dist=c.root_pos_termination_dist, root_rot_termination_angle=c.root_rot_termination_angle))
+    fs = {k: torch.as_tensor(st[k].copy()) for k in ("char_root_pos", "char_root_rot", "char_root_vel", "char_root_ang_vel", "char_dof_pos", "char_dof_vel",
+                                                     "char_body_pos", "contact_forces", "time_offsets")}
+    fs["motion_ids"] = ids; fs["terrain_ids"] = torch.as_tensor(st["terrain_ids"].astype(np.int64))
+    with torch.no_grad():
+        fs["timestep"] = torch.zeros(n, dtype=torch.int32)
+        ks.step(fs)  # warm-up
+        t0 = time.time(); fsteps = 0
+        while fsteps < 2 or (time.time() - t0 < seconds and fsteps < 1000):
+            fs["timestep"] = torch.full((n,), fsteps % 8, dtype=torch.int32)   # stay inside the clips
+            ks.step(fs); fsteps += 1
+        fdt = time.time() - t0
+    out["full_step"] = {"value": n * fsteps / fdt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+                        "sample": f"{fsteps} x {n} envs: PyTorch-CPU op sequence of the reference's whole kinematic step (441-ray height gather, reference frame + FK, 6 targets, "
+                                  "1 312-column observation, DeepMimic reward + contact term, compute_done), torch.set_num_threads(cores); no physics, no fail-rate EMA loop"}
+    return out
 
 
 def _profile_json(suffix, build=None):

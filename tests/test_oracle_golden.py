@@ -451,3 +451,39 @@ def test_action_bounds_vs_reference_golden():
     np.testing.assert_allclose(low, g["action_low"], rtol=0, atol=1e-7)
     np.testing.assert_allclose(high, g["action_high"], rtol=0, atol=1e-7)
     assert (high > low).all()
+
+
+def test_torch_full_step_vs_reference_golden(oracle, orc_char, char_golden):
+    """oracle/torch_path.py::KinematicStep -- the PyTorch-CPU op sequence of the reference's WHOLE `_post_physics_step` (height rays, reference
+    frame + FK, 1 312-column observation, DeepMimic reward + contact term, compute_done + motion end), which bench.py times as
+    `cpu_baseline.torch_full_step` -- against the reference's own outputs on the three consecutive steps of env_step.npz."""
+    import torch
+    from helpers import JOINT_ERR_W, KEY_BODY_IDS, POSE_TERM_DIST, TAR_OBS_STEPS, dof_err_w_from_joint, load_clips, make_orc_mlib
+    from oracle import torch_path as tp
+    g = golden("env_step")
+    cg = char_golden
+    cm = tp.CharModel(cg["parent"], cg["local_translation"], cg["local_rotation"], cg["joint_type"], cg["joint_axis"], cg["dof_idx"], int(cg["dof_size"]))
+    clips = load_clips([str(c) for c in g["clips"]])
+    olib = make_orc_mlib(oracle, orc_char, clips, [1.0, 1.5, 2.0, 2.5])
+    F = sum(c["root_pos"].shape[0] for c in clips)
+    lib = tp.MotionLib(tp.make_tables(clips, oracle.mlib_array(olib, "frame_root_vel", (F, 3)), oracle.mlib_array(olib, "frame_root_ang_vel", (F, 3)),
+                                      oracle.mlib_array(olib, "frame_dof_vel", (F, 28))))
+    ws = np.array([0.5, 0.1, 0.15, 0.1, 0.15]); ws = ws / ws.sum()
+    ks = tp.KinematicStep(cm, lib, tp.Terrain(g["hf"], g["hf_min_point"], g["hf_dxdy"]),
+                          dict(key_body_ids=KEY_BODY_IDS, tar_obs_steps=TAR_OBS_STEPS, ray_points=g["ray_points"], env_offsets=g["env_offsets"],
+                               motion_offsets=g["motion_offsets"], timestep=1.0 / 30.0, episode_length=10.0, min_obs_h=-3.0, max_obs_h=3.0,
+                               reward_weights=ws, joint_err_w=JOINT_ERR_W, dof_err_w=dof_err_w_from_joint(cg, JOINT_ERR_W), contact_weights=[5.0] * 15,
+                               pose_termination_dist=POSE_TERM_DIST, root_pos_termination_dist=0.6, root_rot_termination_angle=1.309))
+    T = lambda a: torch.as_tensor(np.ascontiguousarray(a))
+    for s in range(3):
+        p = "s%d_in_" % s
+        st = {k: T(g[p + k]) for k in ("char_root_pos", "char_root_rot", "char_root_vel", "char_root_ang_vel", "char_dof_pos", "char_dof_vel", "char_body_pos",
+                                       "contact_forces", "time_offsets")}
+        st["motion_ids"] = T(g[p + "motion_ids"]).long(); st["terrain_ids"] = T(g[p + "terrain_ids"]).long(); st["timestep"] = T(g[p + "timestep"]).int()
+        with torch.no_grad():
+            obs, rew, done = ks.step(st)
+        o = "s%d_out_" % s
+        err = np.abs(obs.numpy() - g[o + "obs"])
+        assert err.max() <= 1e-5, (s, err.max(), np.unravel_index(err.argmax(), err.shape))
+        assert np.abs(rew.numpy() - g[o + "reward"]).max() <= 1e-5
+        assert np.array_equal(done.numpy(), g[o + "done"]), s
