@@ -609,10 +609,13 @@ __device__ __forceinline__ void wv_joint_inward(const DynModel &M, const WaveTab
     const int jt = W.c[b].jtype, di = W.c[b].dof_idx;
     const v3 r = B.r;
     if (jt == DJ_SPHERICAL) {
-        s6 Sc[3], Uc[3];
-        float tau[3], aug[3], uu[3];
-        PARC_UNROLL
-        for (int q = 0; q < 3; ++q) { const v3 a = mk(R.m[0][q], R.m[1][q], R.m[2][q]); Sc[q] = s6mk(a, cross(r, a)); }
+        // The elimination of a spherical joint depends on the SUBSPACE its motion vectors span, not on their basis: S = P R with
+        // P = [1; [r]x] (6 x 3) and R the body rotation, so span(S) = span(P) and the world-axis basis P serves -- U' = IA P is 36
+        // multiply-adds instead of the 108 of IA S, D' = P^T U' + R diag(aug) R^T 39 instead of 54, and S itself is never formed
+        // (round 4: -117 of ~560 vector instructions per elimination; parc_dynamics.hpp keeps the joint-frame statement, S = P R:
+        // U = U' R, D = R^T D' R, K = K' R, K u = K' u', I - K U^T = I - K' U'^T -- the same projection up to rounding).  The factors kept
+        // for the outward pass are K' and D'^-1 u' (world axes); the joint-frame acceleration the integrator needs is R^T q'.
+        float tau[3], aug[3];
         const v3 err = qlog(qmul(qconj(B.jq), B.tq));
         const v3 cur = qlog(B.jq);
         const float e3[3] = {err.x, err.y, err.z}, c3[3] = {cur.x, cur.y, cur.z}, q3[3] = {B.qd.x, B.qd.y, B.qd.z};
@@ -625,23 +628,35 @@ __device__ __forceinline__ void wv_joint_inward(const DynModel &M, const WaveTab
             else if (c3[q] > W.c[b].hi[q]) { t += M.lim_k * (W.c[b].hi[q] - c3[q]) - M.lim_d * q3[q]; aug[q] += dt * M.lim_d + dt * dt * M.lim_k; }
             tau[q] = t;
         }
+        // U' = IA P: column j = IA[:, j] + sum_k IA[:, 3 + k] [r]x[k][j],  [r]x = [[0, -rz, ry], [rz, 0, -rx], [-ry, rx, 0]]
+        s6 Uc[3];
         PARC_UNROLL
-        for (int q = 0; q < 3; ++q) {
-            Uc[q] = symmul(IA, Sc[q]);
-            float sp = 0.f;
-            PARC_UNROLL
-            for (int a = 0; a < 6; ++a) sp += Sc[q].a[a] * pA.a[a];
-            uu[q] = tau[q] - sp;
+        for (int a = 0; a < 6; ++a) {
+            const float i3 = sget(IA, a, 3), i4 = sget(IA, a, 4), i5 = sget(IA, a, 5);
+            Uc[0].a[a] = sget(IA, a, 0) + (r.z * i4 - r.y * i5);
+            Uc[1].a[a] = sget(IA, a, 1) + (r.x * i5 - r.z * i3);
+            Uc[2].a[a] = sget(IA, a, 2) + (r.y * i3 - r.x * i4);
         }
+        // u' = R tau - P^T pA,  P^T x = x_ang - [r]x x_lin = x_ang - r x x_lin
+        const v3 tw = mulv(R, mk(tau[0], tau[1], tau[2]));
+        const v3 pl = mk(pA.a[3], pA.a[4], pA.a[5]);
+        const v3 rxp = cross(r, pl);
+        const float uu[3] = {tw.x - (pA.a[0] - rxp.x), tw.y - (pA.a[1] - rxp.y), tw.z - (pA.a[2] - rxp.z)};
+        // D' = P^T U' + R diag(aug) R^T (symmetric: six entries)
         float Dm[3][3];
         PARC_UNROLL
+        for (int l = 0; l < 3; ++l) {
+            const v3 ub = mk(Uc[l].a[3], Uc[l].a[4], Uc[l].a[5]);
+            const v3 rxu = cross(r, ub);
+            Dm[0][l] = Uc[l].a[0] - rxu.x; Dm[1][l] = Uc[l].a[1] - rxu.y; Dm[2][l] = Uc[l].a[2] - rxu.z;
+        }
+        PARC_UNROLL
         for (int q = 0; q < 3; ++q) {
             PARC_UNROLL
-            for (int l = 0; l < 3; ++l) {
-                float a_ = 0.f;
-                PARC_UNROLL
-                for (int a = 0; a < 6; ++a) a_ += Sc[q].a[a] * Uc[l].a[a];
-                Dm[q][l] = a_ + (q == l ? aug[q] : 0.f);
+            for (int l = q; l < 3; ++l) {
+                const float g = R.m[q][0] * aug[0] * R.m[l][0] + R.m[q][1] * aug[1] * R.m[l][1] + R.m[q][2] * aug[2] * R.m[l][2];
+                Dm[q][l] += g;
+                if (l != q) Dm[l][q] = Dm[q][l]; // the exact matrix is symmetric: one triangle decides
             }
         }
         const float c00 = Dm[1][1] * Dm[2][2] - Dm[1][2] * Dm[2][1], c01 = Dm[0][2] * Dm[2][1] - Dm[0][1] * Dm[2][2],
@@ -723,8 +738,8 @@ __device__ __forceinline__ void wv_joint_outward(const DynModel &M, const WaveTa
             for (int a = 0; a < 6; ++a) ka += fac[(6 * q + a) * FS] * ai.a[a];
             q3[q] = fac[(18 + q) * FS] - ka;
         }
-        B.qdd = mk(q3[0], q3[1], q3[2]);
-        const v3 wj = mulv(qmat(B.bq), B.qdd);
+        const v3 wj = mk(q3[0], q3[1], q3[2]);       // the joint's angular acceleration in WORLD axes (the factors are K', D'^-1 u': wv_joint_inward)
+        B.qdd = mulTv(qmat(B.bq), wj);               // ... and in the joint (child) frame, which the integrator advances
         ai = ai + s6mk(wj, cross(B.r, wj));
     } else if (jt == DJ_HINGE) {
         float ka = 0.f;
