@@ -53,7 +53,9 @@ struct WvBodyC {
     float bc[3], pad2;
     float kp[3], kd[3], arm[3], eff[3], lo[3], hi[3], act_lo[3], act_hi[3]; // the joint's dofs (hinge: [0])
     int nsg, sg0;            // collision segments of the body (capsule axes / sole edges, DynModel::seg_*)
-    float pad3[6];
+    int own_npt, child;      // a FIXED leaf body merged into this one (the humanoid's hands into the lower arms, build_wave_tables): its collision
+                             // points are this body's points [own_npt, npt), its index `child` (-1: none) receives their contact force
+    float pad3[4];
 };
 static_assert(sizeof(WvBodyC) == 256, "WvBodyC is one 256-byte record");
 
@@ -119,6 +121,24 @@ inline bool build_wave_tables(const DynModel &M, const CoopTables &C, WaveTables
         W.len[c] = C.len[c];
         for (int k = 0; k < C.len[c]; ++k) W.body[c][k] = C.body[c][k];
     }
+    // A leaf body on a FIXED joint is a rigid part of its parent: the articulated-body recursion through a fixed joint only adds the
+    // child's inertia, bias and contact wrench to the parent's.  Merging it at table-build time (composite mass, centre of mass and
+    // inertia in the parent's frame; its collision points moved into the parent's frame) removes one body from the limb's kinematics,
+    // own-inertia and elimination passes -- the humanoid's hands: -1 of 3 bodies on the two arm waves, of which wave 0 is the critical
+    // one.  The contact force of the child is still reported on its own (the observation's contact flags are per body).
+    int merged_child[DYN_MAXB];
+    for (int b = 0; b < DYN_MAXB; ++b) merged_child[b] = -1;
+    for (int c = 1; c < C.nchain; ++c) {
+        const int L = W.len[c];
+        if (L < 2) continue;
+        const int bl = W.body[c][L - 1], bp = W.body[c][L - 2];
+        bool leaf = M.jtype[bl] == DJ_FIXED && M.parent[bl] == bp && C.nchild[bl] == 0 && C.nsg[bl] == 0 &&
+                    (C.npt[bl] == 0 || (C.npt[bp] > 0 && C.pt0[bl] == C.pt0[bp] + C.npt[bp]));
+        for (int b = 0; b < M.B; ++b) if (M.parent[b] == bl) leaf = false;
+        if (!leaf) continue;
+        merged_child[bp] = bl;
+        W.len[c] = L - 1;
+    }
     int natt = 0;
     for (int k = 0; k < WV_MAXLEN; ++k) W.att_slot[k] = -1;
     for (int c = 1; c < C.nchain; ++c) {
@@ -130,21 +150,41 @@ inline bool build_wave_tables(const DynModel &M, const CoopTables &C, WaveTables
         W.early[c] = pos > 0;
         W.child[pos][W.nchild[pos]++] = c;
     }
+    // collision tables in the frame of the body that carries them (a merged child's points move into its parent's frame)
+    for (int k = 0; k < M.ncol; ++k) { for (int a = 0; a < 3; ++a) W.colp[k][a] = M.col_pos[k][a]; W.colp[k][3] = M.col_r[k]; }
+    for (int k = 0; k < M.nseg; ++k) { for (int a = 0; a < 3; ++a) { W.seg[k][a] = M.seg_a[k][a]; W.seg[k][4 + a] = M.seg_b[k][a]; } W.seg[k][3] = M.seg_r[k]; }
+    double mrot[DYN_MAXB][3][3];
+    for (int b = 0; b < M.B; ++b) { // rotation of body b's fixed local rotation lr (xyzw), used for merged children
+        const double x = M.lr[b][0], y = M.lr[b][1], z = M.lr[b][2], w_ = M.lr[b][3];
+        const double Rq[3][3] = {{1 - 2 * (y * y + z * z), 2 * (x * y - z * w_), 2 * (x * z + y * w_)}, {2 * (x * y + z * w_), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w_)},
+                                 {2 * (x * z - y * w_), 2 * (y * z + x * w_), 1 - 2 * (x * x + y * y)}};
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) mrot[b][i][j] = Rq[i][j];
+    }
     for (int b = 0; b < M.B; ++b) {
         W.npt[b] = C.npt[b]; W.pt0[b] = C.pt0[b]; W.brad[b] = C.brad[b];
+        const int ch = merged_child[b];
+        if (ch >= 0) {
+            for (int i = 0; i < C.npt[ch]; ++i) {
+                const int k = C.pt0[ch] + i;
+                for (int a = 0; a < 3; ++a)
+                    W.colp[k][a] = (float)(M.lt[ch][a] + mrot[ch][a][0] * M.col_pos[k][0] + mrot[ch][a][1] * M.col_pos[k][1] + mrot[ch][a][2] * M.col_pos[k][2]);
+            }
+            if (C.npt[b] == 0) W.pt0[b] = C.pt0[ch];
+            W.npt[b] = C.npt[b] + C.npt[ch];
+        }
         float lo[3] = {0.f, 0.f, 0.f}, hi[3] = {0.f, 0.f, 0.f};
-        for (int i = 0; i < C.npt[b]; ++i)
+        for (int i = 0; i < W.npt[b]; ++i)
             for (int a = 0; a < 3; ++a) {
-                const float v = M.col_pos[C.pt0[b] + i][a];
+                const float v = W.colp[W.pt0[b] + i][a];
                 if (i == 0 || v < lo[a]) lo[a] = v;
                 if (i == 0 || v > hi[a]) hi[a] = v;
             }
         float rho = 0.f;
         for (int a = 0; a < 3; ++a) W.bc[b][a] = 0.5f * (lo[a] + hi[a]);
-        for (int i = 0; i < C.npt[b]; ++i) {
-            const float *q = M.col_pos[C.pt0[b] + i];
+        for (int i = 0; i < W.npt[b]; ++i) {
+            const float *q = W.colp[W.pt0[b] + i];
             const float d = sqrtf((q[0] - W.bc[b][0]) * (q[0] - W.bc[b][0]) + (q[1] - W.bc[b][1]) * (q[1] - W.bc[b][1]) + (q[2] - W.bc[b][2]) * (q[2] - W.bc[b][2]));
-            if (d + M.col_r[C.pt0[b] + i] > rho) rho = d + M.col_r[C.pt0[b] + i];
+            if (d + q[3] > rho) rho = d + q[3];
         }
         W.brho[b] = rho * 1.0001f + 1e-6f;
     }
@@ -176,8 +216,8 @@ inline bool build_wave_tables(const DynModel &M, const CoopTables &C, WaveTables
     {   // LDS shares of the plane lists: two slots each, the rest in proportion to the candidates a wave discovers
         int cand[WV_MAXLIMB] = {0, 0, 0, 0}, tot = 0, used = 0;
         for (int w = 0; w < WV_MAXLIMB; ++w) {
-            if (w < W.nlimb) for (int k = 0; k < W.len[w + 1]; ++k) cand[w] += C.npt[W.body[w + 1][k]] + C.nsg[W.body[w + 1][k]];
-            for (int k = 0; k < W.len[0]; ++k) if (W.rec_wave[k] == w || (w == 0 && W.rec_wave[k] < 0)) cand[w] += C.npt[W.body[0][k]] + C.nsg[W.body[0][k]];
+            if (w < W.nlimb) for (int k = 0; k < W.len[w + 1]; ++k) cand[w] += W.npt[W.body[w + 1][k]] + C.nsg[W.body[w + 1][k]];
+            for (int k = 0; k < W.len[0]; ++k) if (W.rec_wave[k] == w || (w == 0 && W.rec_wave[k] < 0)) cand[w] += W.npt[W.body[0][k]] + C.nsg[W.body[0][k]];
             tot += cand[w];
         }
         for (int w = 0; w < WV_MAXLIMB; ++w) { W.man_cap[w] = 2 + (tot > 0 ? (WV_MAN_TOTAL - 2 * WV_MAXLIMB) * cand[w] / tot : 0); used += W.man_cap[w]; }
@@ -187,10 +227,31 @@ inline bool build_wave_tables(const DynModel &M, const CoopTables &C, WaveTables
     for (int b = 0; b < M.B; ++b) {
         WvBodyC &c = W.c[b];
         c.jtype = M.jtype[b]; c.dof_idx = M.dof_idx[b]; c.npt = W.npt[b]; c.pt0 = W.pt0[b];
+        c.own_npt = C.npt[b]; c.child = merged_child[b];
         c.mass = M.mass[b]; c.brho = W.brho[b];
         for (int a = 0; a < 3; ++a) { c.lt[a] = M.lt[b][a]; c.axis[a] = M.axis[b][a]; c.com[a] = M.com[b][a]; c.bc[a] = W.bc[b][a]; }
         for (int a = 0; a < 4; ++a) c.lr[a] = M.lr[b][a];
         for (int a = 0; a < 6; ++a) c.inertia[a] = M.inertia[b][a];
+        if (merged_child[b] >= 0) { // composite of b and its fixed leaf: mass, centre of mass, inertia about the composite centre, b's frame
+            const int ch = merged_child[b];
+            const double mp = M.mass[b], mc = M.mass[ch], mt = mp + mc;
+            double cc[3], cm[3];
+            for (int a = 0; a < 3; ++a) cc[a] = M.lt[ch][a] + mrot[ch][a][0] * M.com[ch][0] + mrot[ch][a][1] * M.com[ch][1] + mrot[ch][a][2] * M.com[ch][2];
+            for (int a = 0; a < 3; ++a) cm[a] = (mp * M.com[b][a] + mc * cc[a]) / mt;
+            auto full = [](const float *i6, double I[3][3]) { I[0][0] = i6[0]; I[1][1] = i6[1]; I[2][2] = i6[2]; I[0][1] = I[1][0] = i6[3]; I[0][2] = I[2][0] = i6[4]; I[1][2] = I[2][1] = i6[5]; };
+            double Ip[3][3], Ic0[3][3], Icr[3][3], tmp[3][3], It[3][3];
+            full(M.inertia[b], Ip); full(M.inertia[ch], Ic0);
+            for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { tmp[i][j] = 0; for (int k = 0; k < 3; ++k) tmp[i][j] += mrot[ch][i][k] * Ic0[k][j]; }
+            for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { Icr[i][j] = 0; for (int k = 0; k < 3; ++k) Icr[i][j] += tmp[i][k] * mrot[ch][j][k]; }
+            const double dp[3] = {M.com[b][0] - cm[0], M.com[b][1] - cm[1], M.com[b][2] - cm[2]}, dc[3] = {cc[0] - cm[0], cc[1] - cm[1], cc[2] - cm[2]};
+            const double dp2 = dp[0] * dp[0] + dp[1] * dp[1] + dp[2] * dp[2], dc2 = dc[0] * dc[0] + dc[1] * dc[1] + dc[2] * dc[2];
+            for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j)
+                It[i][j] = Ip[i][j] + mp * ((i == j ? dp2 : 0.0) - dp[i] * dp[j]) + Icr[i][j] + mc * ((i == j ? dc2 : 0.0) - dc[i] * dc[j]);
+            c.mass = (float)mt;
+            for (int a = 0; a < 3; ++a) c.com[a] = (float)cm[a];
+            c.inertia[0] = (float)It[0][0]; c.inertia[1] = (float)It[1][1]; c.inertia[2] = (float)It[2][2];
+            c.inertia[3] = (float)It[0][1]; c.inertia[4] = (float)It[0][2]; c.inertia[5] = (float)It[1][2];
+        }
         const int nd = b == 0 ? 0 : (M.jtype[b] == DJ_SPHERICAL ? 3 : (M.jtype[b] == DJ_HINGE ? 1 : 0));
         for (int q = 0; q < nd; ++q) {
             const int d = M.dof_idx[b] + q;
@@ -198,11 +259,9 @@ inline bool build_wave_tables(const DynModel &M, const CoopTables &C, WaveTables
             c.act_lo[q] = M.act_lo[d]; c.act_hi[q] = M.act_hi[d];
         }
     }
-    for (int k = 0; k < M.ncol; ++k) { for (int a = 0; a < 3; ++a) W.colp[k][a] = M.col_pos[k][a]; W.colp[k][3] = M.col_r[k]; }
-    for (int k = 0; k < M.nseg; ++k) { for (int a = 0; a < 3; ++a) { W.seg[k][a] = M.seg_a[k][a]; W.seg[k][4 + a] = M.seg_b[k][a]; } W.seg[k][3] = M.seg_r[k]; }
     for (int b = 0; b < M.B; ++b) {
         W.c[b].nsg = C.nsg[b]; W.c[b].sg0 = C.sg0[b];
-        if (C.npt[b] + C.nsg[b] > 32) return false;
+        if (W.npt[b] + C.nsg[b] > 32) return false;
     }
     return true;
 }
@@ -251,11 +310,12 @@ struct WvBody { // per-body registers of the owning lane
     q4 jq, tq; float hang, thang; v3 qd; // joint state (spherical: quaternion + child-frame omega; hinge: angle + rate)
     q4 bq; v3 r; s6 vel, cJ;             // kinematics of the current substep (common frame, origin = root)
     v3 fcon, qdd;
+    v3 fcon_c;                           // contact force on the fixed leaf merged into this body (WvBodyC::child)
 };
 
 __device__ __forceinline__ void wv_load_joint(const DynModel &M, const WaveTables &W, int b, WvBody &B, const float *dp, const float *dv, const float *ac) {
     B.jq.x = 0.f; B.jq.y = 0.f; B.jq.z = 0.f; B.jq.w = 1.f; B.tq = B.jq; B.hang = 0.f; B.thang = 0.f; B.qd = mk(0.f, 0.f, 0.f);
-    B.fcon = mk(0.f, 0.f, 0.f); B.qdd = mk(0.f, 0.f, 0.f);
+    B.fcon = mk(0.f, 0.f, 0.f); B.qdd = mk(0.f, 0.f, 0.f); B.fcon_c = mk(0.f, 0.f, 0.f);
     const int jt = W.c[b].jtype, di = W.c[b].dof_idx;
     if (jt == DJ_SPHERICAL) {
         B.jq = qexp(mk(dp[di], dp[di + 1], dp[di + 2]));
@@ -401,7 +461,7 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
         // sides are at least half a cell away); whether a candidate is emitted stays with sphere_vs_column / own_column_contact and the
         // margin test, so the result equals sphere_discover's exhaustive 9-column test (parc_dynamics.hpp).  Lanes with a point outside the
         // staged patch (or a sphere too wide for the near-side argument) take that exhaustive path below.
-        const int npt = W.c[b].npt, pt0 = W.c[b].pt0, nsg = W.c[b].nsg, sg0 = W.c[b].sg0;
+        const int npt = W.c[b].npt, pt0 = W.c[b].pt0, nsg = W.c[b].nsg, sg0 = W.c[b].sg0, own_npt = W.c[b].own_npt;
         const float hx = 0.5f * Tp.dx, hy = 0.5f * Tp.dy;
         bool slow = false;
         int n_new = 0; // planes this lane has pushed for the body
@@ -505,7 +565,7 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
                 cnt_pairs += __popcll(__ballot(mine)); cnt_exec += __any(mine) ? 1 : 0;
 #endif
                 if (__any(mine)) { // uniform
-                    if (mine) narrow(pb, x, g, cur.r, 1.f);
+                    if (mine) narrow(pb, x, g, cur.r, pi < own_npt ? 1.f : -1.f); // a negative weight marks a plane of the merged fixed leaf (|w| acts)
                 }
                 cur = nxt;
             }
@@ -534,6 +594,7 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
                     pb = mk(W.colp[kp][0], W.colp[kp][1], W.colp[kp][2]);
                     x = r + mulv(R, pb);
                     rad = W.colp[kp][3];
+                    if (pi >= own_npt) wq = -1.f;
                 } else {
                     v3 Q = rootp;
                     wq = seg_point_slow(sg0 + pi - npt, Q);
@@ -563,7 +624,7 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
     }
     // ---- evaluation of the body's planes: x = r + R p, pen = off - n . (x + rootp); contact_apply on pen > 0 (the shared statement of
     // parc_dynamics.hpp).  Slots [cur, cur + n) of the lane's list; the trip count is the largest n in the wave.
-    v3 fsum = mk(0.f, 0.f, 0.f);
+    v3 fsum = mk(0.f, 0.f, 0.f), fsum_c = mk(0.f, 0.f, 0.f);
     {
         const int n_me = (int)((man.cnt >> site6) & 63ull);
         // plane t of the lane (valid address for every lane: slot 0 when it has no plane t)
@@ -592,12 +653,17 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
                 const v3 vpt = s6lin(B.vel) + cross(s6ang(B.vel), x);
                 // (tried in round 4, both slower by 3 %: a short form for normals that are exactly +z behind an __all test -- two code paths
                 // instead of one --, and fetching plane t + 1 while plane t is evaluated -- eight more live registers and their copies)
-                if (hit) contact_apply(M, dt, x, vpt, pen, n, IA, pA, fsum, e_[7]);
+                if (hit) {
+                    v3 f1 = mk(0.f, 0.f, 0.f);
+                    contact_apply(M, dt, x, vpt, pen, n, IA, pA, f1, fabsf(e_[7]));
+                    const bool own = e_[7] > 0.f;
+                    fsum = fsum + (own ? f1 : mk(0.f, 0.f, 0.f)); fsum_c = fsum_c + (own ? mk(0.f, 0.f, 0.f) : f1);
+                }
             }
         }
         man.cur += n_me;
     }
-    B.fcon = fsum;
+    B.fcon = fsum; B.fcon_c = fsum_c;
     WPIN(IA, pA);
     WSTAMP(4);  // evaluation of the body's planes
 }
@@ -783,6 +849,12 @@ __device__ __forceinline__ void wv_store_joint(const DynModel &M, const WaveTabl
         pr[b] = make_float4(0.f, 0.f, 0.f, 1.f);
     }
     cf[3 * b] = fc.x; cf[3 * b + 1] = fc.y; cf[3 * b + 2] = fc.z;
+    const int ch = W.c[b].child; // the fixed leaf merged into this body: its contact force, its (identity) prep-record quaternion
+    if (ch >= 0) {
+        const v3 fcc = B.fcon_c;
+        cf[3 * ch] = fcc.x; cf[3 * ch + 1] = fcc.y; cf[3 * ch + 2] = fcc.z;
+        if (pr) pr[ch] = make_float4(0.f, 0.f, 0.f, 1.f);
+    }
 }
 
 __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__restrict__ Mp, const WaveTables *__restrict__ Wp, DynTerrain T,

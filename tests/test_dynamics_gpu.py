@@ -115,6 +115,7 @@ def test_wave_kernel_vs_coop_on_a_slice_of_the_cfg3_scene(tmp_path, monkeypatch)
     assert np.array_equal(big._scene.env_offsets[:ns], small._scene.env_offsets)
     gen = torch.Generator(device="cuda:0"); gen.manual_seed(8)
     big.reset()
+    hand_contacts = 0
     for it in range(12):  # let the population spread out (falls, wall contacts, resets)
         big.step(_bench_actions(big, gen)); big.reset_done()
     state = ["_char_root_pos", "_char_root_rot", "_char_root_vel", "_char_root_ang_vel", "_char_dof_pos", "_char_dof_vel"]
@@ -139,8 +140,15 @@ def test_wave_kernel_vs_coop_on_a_slice_of_the_cfg3_scene(tmp_path, monkeypatch)
         fa, fb = to_np(big._char_contact_forces)[:ns], to_np(small._char_contact_forces)
         ferr = np.abs(fa - fb).reshape(ns, -1).max(1)
         assert np.quantile(ferr, 0.99) <= 1.0 + 1e-3 * np.abs(fa).max(), (it, np.quantile(ferr, 0.99), ferr.max())
+        # the hands (fixed joints) are merged into the lower arms inside k_dynamics_wave (build_wave_tables) and still report their own
+        # contact force: their flags must agree with the kernel that keeps them as bodies of their own
+        hands = [5, 8]
+        ha, hb = np.linalg.norm(fa[:, hands], axis=-1) > 1e-5, np.linalg.norm(fb[:, hands], axis=-1) > 1e-5
+        assert (ha == hb).mean() > 0.998, (it, (ha == hb).mean())
+        hand_contacts += int(hb.sum())
         assert np.array_equal(to_np(big._done_buf)[:ns] != 0, to_np(small._done_buf) != 0) or \
             np.mean((to_np(big._done_buf)[:ns] != 0) != (to_np(small._done_buf) != 0)) < 1e-3
+    assert hand_contacts > 50, hand_contacts     # the scenario does put hands on the ground
 
 
 def physx_replay_metrics(n=32, clip="dec2024_teaser_717_1_opt_dm"):
