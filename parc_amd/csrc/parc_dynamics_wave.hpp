@@ -652,18 +652,21 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
             if (__any(hit)) {
                 const v3 vpt = s6lin(B.vel) + cross(s6ang(B.vel), x);
                 // (tried in round 4, both slower by 3 %: a short form for normals that are exactly +z behind an __all test -- two code paths
-                // instead of one --, and fetching plane t + 1 while plane t is evaluated -- eight more live registers and their copies)
+                // instead of one --, and fetching plane t + 1 while plane t is evaluated -- eight more live registers and their copies; the latter
+                // again +2.7 % after the legs had become the critical waves)
+                // (tried in round 4, +0.6 %: the planes of a body partitioned after discovery, touching ones first, so that the late rounds
+                // hold only speculative planes and skip the force law -- the rounds still find a penetrating lane, the partition costs)
                 if (hit) {
                     v3 f1 = mk(0.f, 0.f, 0.f);
                     contact_apply(M, dt, x, vpt, pen, n, IA, pA, f1, fabsf(e_[7]));
-                    const bool own = e_[7] > 0.f;
-                    fsum = fsum + (own ? f1 : mk(0.f, 0.f, 0.f)); fsum_c = fsum_c + (own ? mk(0.f, 0.f, 0.f) : f1);
+                    fsum = fsum + f1;                                      // own + merged leaf; the leaf's share is taken out below
+                    if (e_[7] < 0.f) fsum_c = fsum_c + f1;
                 }
             }
         }
         man.cur += n_me;
     }
-    B.fcon = fsum; B.fcon_c = fsum_c;
+    B.fcon = fsum - fsum_c; B.fcon_c = fsum_c; // (the same addends in the same order: a body whose only contacts are its leaf's reports exactly 0)
     WPIN(IA, pA);
     WSTAMP(4);  // evaluation of the body's planes
 }
