@@ -75,6 +75,7 @@ struct StepParams {
     int N, B, J, D, K, S, R, M, T;
     int lds_wave_floats; // dynamic LDS per wave of k_env_post
     int global_obs, off_char; // read by the OBSVAR instantiations of k_env_post only
+    int lr_identity;          // every joint's fixed local rotation is the identity (the humanoid): lr (x) q = q, no quaternion product in the row phase
     int obs_tar, obs_contact; // OBSVAR only: 0 = the target block (+ target contacts) / the contact blocks and the reward's contact term are off
     int obs_dim, off_dofvel, off_key, off_tar, tar_w, off_tarc, off_cc, off_hf;
     float dt_f, episode_length, min_obs_h, max_obs_h;
@@ -548,7 +549,7 @@ __global__ __launch_bounds__(256, 5) void k_env_post(const StepParams P, const i
             }
             if (i >= 1 && i < B) { // the FK chains multiply parent (x) (lr (x) q): the inner product is formed here, once per joint,
                                    // instead of once per chain level (same operations, same order)
-                const Q4 lq = quat_mul(mk4(s_tab.lr[i][0], s_tab.lr[i][1], s_tab.lr[i][2], s_tab.lr[i][3]), res);
+                const Q4 lq = P.lr_identity ? res : quat_mul(mk4(s_tab.lr[i][0], s_tab.lr[i][1], s_tab.lr[i][2], s_tab.lr[i][3]), res);
                 if (r < 2) { s_lq[r][i] = lq; s_q[r][i] = res; } else s_q[r][i] = lq;
             } else {
                 s_q[r][i] = res;
@@ -1749,6 +1750,9 @@ extern "C" int parc_env_create(const ParcEnvConfig *cfg, ParcEnv **out) {
     sp.off_key = sp.off_dofvel + D;
     sp.off_tar = sp.off_key + 3 * K;
     sp.tar_w = 3 + 6 + 6 * J + 3 * K;
+    sp.lr_identity = 1;
+    for (int b = 0; b < B; ++b)
+        if (!(cfg->model.local_rotation[b][0] == 0.f && cfg->model.local_rotation[b][1] == 0.f && cfg->model.local_rotation[b][2] == 0.f && cfg->model.local_rotation[b][3] == 1.f)) sp.lr_identity = 0;
     sp.obs_tar = cfg->enable_tar_obs != 0; sp.obs_contact = cfg->use_contact_info != 0;
     sp.off_tarc = sp.off_tar + (sp.obs_tar ? S * sp.tar_w : 0);          // ig_parkour_env.py:927-946: the blocks that exist, in this order
     sp.off_cc = sp.off_tarc + (sp.obs_tar && sp.obs_contact ? S * B : 0);
