@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PARC_ABI_VERSION 5
+#define PARC_ABI_VERSION 6
 #define PARC_MAX_BODIES 16   /* 15 quats + root position share one 16-lane group */
 #define PARC_MAX_DOFS 40     /* dof velocities live in floats [88,128) of a 128-float frame record */
 #define PARC_MAX_TAR_STEPS 6 /* 2 + steps skeletons <= 8 lane groups of 8 */
@@ -65,6 +65,16 @@ typedef struct {
 
 /* Rigid-body / actuator parameters the reference hands to Isaac Gym through the MJCF
  * (ig_char_env.py:100-143, humanoid.xml) and the sim block of dm_env_default.yaml:175-186. */
+/* ControlMode of the reference (ig_char_env.py:21-26).  pd: the action is the PD position target (exp-map per spherical joint), clipped to the action
+ * bounds (implicit drive, PhysX DOF_MODE_POS).  vel: velocity target, drive force = damping * (action - dof_vel) (DOF_MODE_VEL, stiffness 0).  torque: the
+ * clipped action is the joint torque (DOF_MODE_EFFORT).  pd_exp / pd_1d: the explicit PD torque of ig_char_env.py:399-421, computed once per control
+ * step from the state at its start, target = the action as given (not clipped, :500-503), limited to the motor efforts; pd_1d needs a character
+ * whose joints all have one dof (the reference asserts it, :246-250). */
+#define PARC_CTRL_PD 0
+#define PARC_CTRL_VEL 1
+#define PARC_CTRL_TORQUE 2
+#define PARC_CTRL_PD_EXP 3
+#define PARC_CTRL_PD_1D 4
 typedef struct {
     int32_t num_geoms;
     int32_t geom_body[PARC_MAX_GEOMS];
@@ -90,6 +100,7 @@ typedef struct {
     float max_depenetration_velocity;
     float angular_damping;               /* ig_char_env.py:142 */
     float max_angular_velocity;          /* ig_char_env.py:143 */
+    int32_t control_mode;                /* env.control_mode (ig_char_env.py:21-26,95): PARC_CTRL_*; what `action` means (ig_char_env.py:488-506) */
 } ParcDynamicsParams;
 
 /* Environment constants — the keys IGParkourEnv.__init__ reads (ig_parkour_env.py:43-149). */

@@ -40,11 +40,13 @@
 #if defined(__HIP_DEVICE_COMPILE__)
 #define DYN_RCP(x) __builtin_amdgcn_rcpf(x)
 #define DYN_SQRT(x) __builtin_amdgcn_sqrtf(x)
+#define DYN_RINT(x) __builtin_rintf(x)
 #define DYN_SIN(x) __sinf(x)
 #define DYN_COS(x) __cosf(x)
 #else
 #define DYN_RCP(x) (1.f / (x))
 #define DYN_SQRT(x) sqrtf(x)
+#define DYN_RINT(x) rintf(x)
 #define DYN_SIN(x) sinf(x)
 #define DYN_COS(x) cosf(x)
 #endif
@@ -105,6 +107,8 @@ struct DynModel {
     float lim_k, lim_d;          // joint-limit penalty
     float max_ang_vel, ang_damping;
     float total_mass;
+    int ctrl;                    // control mode (PARC_CTRL_*, ig_char_env.py:21-26): 0 = pd, the implicit drive towards the action's pose; the others
+                                 // turn the action into a feed-forward joint torque that is constant over the control step (ctrl_ff / drive_ff below)
     int truncated;               // collision points / segments / mass parts that did not fit the fixed tables (DYN_MAXC / DYN_MAXS / 64): the model
                                  // would depend on the geom order -- parc_env_create refuses such a model
     float ext_acc[2];            // TEST HOOK of the host build (oracle/dyn_oracle.cpp): uniform horizontal acceleration, i.e. a tilted gravity
@@ -449,6 +453,31 @@ struct DynState { // pointers to this env's rows
 
 PARC_HD float clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
+// Control modes other than pd (ig_char_env.py:488-506, 374-421).  One dof's FEED-FORWARD torque, formed once per control step:
+//   vel     velocity target: PhysX's drive force is damping * (target - dof_vel) with the stiffness set to 0 (:122-123): damping * target is the
+//           constant part, -damping * dof_vel stays in the (implicit) drive;
+//   torque  the action clipped to its bounds (= +- the motor efforts, :361-368) is the joint torque (:378-380, 498-499);
+//   pd_exp, pd_1d   explicit PD torque from the state at the start of the control step (_apply_forces runs once per _step_sim, :374-397); `diff` is
+//           the rotation from the joint's pose to the target's as an exponential map (pd_exp, compute_dof_vel with dt = 1, :404-409) or the plain
+//           difference (pd_1d, :419); the target is the action AS GIVEN (:500-503 store `actions`, not the clipped copy); limited to the motor efforts.
+PARC_HD float ctrl_ff(int ctrl, float kp, float kd, float eff, float act_lo, float act_hi, float a, float diff, float qd0) {
+    if (ctrl == PARC_CTRL_VEL) return kd * clampf(a, act_lo, act_hi);
+    if (ctrl == PARC_CTRL_TORQUE) return clampf(a, act_lo, act_hi);
+    return clampf(kp * diff - kd * qd0, -eff, eff);
+}
+// a hinge's `diff`: pd_exp goes through quaternions (the shorter way round), pd_1d subtracts
+PARC_HD float ctrl_hinge_diff(int ctrl, float a, float hang) {
+    float d = a - hang;
+    if (ctrl == PARC_CTRL_PD_EXP) d -= 6.28318530717958648f * DYN_RINT(d * 0.159154943091895336f);
+    return d;
+}
+// ... and the substep's drive torque / joint-space augmentation with it (the pd mode's are kp err - (kd + dt kp) qd and arm + dt kd + dt^2 kp)
+PARC_HD void drive_ff(int ctrl, float kd, float arm, float eff, float dt, float ff, float qd, float &t, float &aug) {
+    const float kdv = ctrl == PARC_CTRL_VEL ? kd : 0.f;
+    t = clampf(ff - kdv * qd, -eff, eff);
+    aug = arm + dt * kdv;
+}
+
 // Advance one env by one CONTROL step (nsub solver substeps).  `action` = PD targets before clipping
 // (ig_char_env.py:488-490); env_off = origin of the env in the global terrain frame.
 PARC_HD void dyn_control_step(const DynModel &M, const DynTerrain &T, const DynState &S, const float *action, const float *env_off) {
@@ -466,16 +495,27 @@ PARC_HD void dyn_control_step(const DynModel &M, const DynTerrain &T, const DynS
     q4 tq[DYN_MAXB];      // PD target rotation
     float thang[DYN_MAXB];
     for (int d = 0; d < M.D; ++d) qd[d] = S.dof_vel[d];
+    float ff[DYN_MAXD];   // feed-forward joint torques of the control modes other than pd
+    for (int d = 0; d < DYN_MAXD; ++d) ff[d] = 0.f;
     for (int i = 1; i < B; ++i) {
         const int di = M.dof_idx[i];
         jq[i].x = 0.f; jq[i].y = 0.f; jq[i].z = 0.f; jq[i].w = 1.f; hang[i] = 0.f; tq[i] = jq[i]; thang[i] = 0.f;
         if (M.jtype[i] == DJ_SPHERICAL) {
             jq[i] = qexp(mk(S.dof_pos[di], S.dof_pos[di + 1], S.dof_pos[di + 2]));
-            tq[i] = qexp(mk(clampf(action[di], M.act_lo[di], M.act_hi[di]), clampf(action[di + 1], M.act_lo[di + 1], M.act_hi[di + 1]),
-                            clampf(action[di + 2], M.act_lo[di + 2], M.act_hi[di + 2])));
+            if (M.ctrl == PARC_CTRL_PD) {
+                tq[i] = qexp(mk(clampf(action[di], M.act_lo[di], M.act_hi[di]), clampf(action[di + 1], M.act_lo[di + 1], M.act_hi[di + 1]),
+                                clampf(action[di + 2], M.act_lo[di + 2], M.act_hi[di + 2])));
+            } else {
+                v3 diff = mk(0.f, 0.f, 0.f);
+                if (M.ctrl >= PARC_CTRL_PD_EXP) diff = qlog(qmul(qconj(jq[i]), qexp(mk(action[di], action[di + 1], action[di + 2]))));
+                const float d3[3] = {diff.x, diff.y, diff.z};
+                for (int k = 0; k < 3; ++k)
+                    ff[di + k] = ctrl_ff(M.ctrl, M.kp[di + k], M.kd[di + k], M.eff[di + k], M.act_lo[di + k], M.act_hi[di + k], action[di + k], d3[k], qd[di + k]);
+            }
         } else if (M.jtype[i] == DJ_HINGE) {
             hang[i] = S.dof_pos[di];
-            thang[i] = clampf(action[di], M.act_lo[di], M.act_hi[di]);
+            if (M.ctrl == PARC_CTRL_PD) thang[i] = clampf(action[di], M.act_lo[di], M.act_hi[di]);
+            else ff[di] = ctrl_ff(M.ctrl, M.kp[di], M.kd[di], M.eff[di], M.act_lo[di], M.act_hi[di], action[di], ctrl_hinge_diff(M.ctrl, action[di], hang[i]), qd[di]);
         }
     }
     Patch patch;
@@ -597,6 +637,7 @@ PARC_HD void dyn_control_step(const DynModel &M, const DynTerrain &T, const DynS
                     float t = M.kp[di + k] * e3[k] - (M.kd[di + k] + dt * M.kp[di + k]) * qd[di + k];
                     t = clampf(t, -M.eff[di + k], M.eff[di + k]);
                     aug[k] = M.arm[di + k] + dt * M.kd[di + k] + dt * dt * M.kp[di + k];
+                    if (M.ctrl != PARC_CTRL_PD) drive_ff(M.ctrl, M.kd[di + k], M.arm[di + k], M.eff[di + k], dt, ff[di + k], qd[di + k], t, aug[k]);
                     if (c3[k] < M.lo[di + k]) { t += M.lim_k * (M.lo[di + k] - c3[k]) - M.lim_d * qd[di + k]; aug[k] += dt * M.lim_d + dt * dt * M.lim_k; }
                     else if (c3[k] > M.hi[di + k]) { t += M.lim_k * (M.hi[di + k] - c3[k]) - M.lim_d * qd[di + k]; aug[k] += dt * M.lim_d + dt * dt * M.lim_k; }
                     tau[k] = t;
@@ -607,6 +648,7 @@ PARC_HD void dyn_control_step(const DynModel &M, const DynTerrain &T, const DynS
                 float t = M.kp[di] * (thang[i] - hang[i]) - (M.kd[di] + dt * M.kp[di]) * qd[di];
                 t = clampf(t, -M.eff[di], M.eff[di]);
                 aug[0] = M.arm[di] + dt * M.kd[di] + dt * dt * M.kp[di];
+                if (M.ctrl != PARC_CTRL_PD) drive_ff(M.ctrl, M.kd[di], M.arm[di], M.eff[di], dt, ff[di], qd[di], t, aug[0]);
                 if (hang[i] < M.lo[di]) { t += M.lim_k * (M.lo[di] - hang[i]) - M.lim_d * qd[di]; aug[0] += dt * M.lim_d + dt * dt * M.lim_k; }
                 else if (hang[i] > M.hi[di]) { t += M.lim_k * (M.hi[di] - hang[i]) - M.lim_d * qd[di]; aug[0] += dt * M.lim_d + dt * dt * M.lim_k; }
                 tau[0] = t;
@@ -889,6 +931,7 @@ inline void fill_dyn_model(DynModel &M, const ParcCharModel &cm, const ParcDynam
     M.pen_cap = (dp.max_depenetration_velocity > 0.f ? dp.max_depenetration_velocity : 10.f) * M.dn / M.kn;
     // manifold: discovery once per control step; margin = PhysX's contact_offset + 1.5 x what a point covers at its approach speed until the
     // next discovery, capped so that (largest sphere + margin) stays under half a cell (the near-side-only neighbour logic of the wave kernel)
+    M.ctrl = dp.control_mode;
     M.man_period = M.nsub;
     M.spec_m0 = dp.contact_offset > 0.f ? dp.contact_offset : 0.02f;
     M.spec_tv = 1.5f * (float)(M.man_period - 1) * M.dt;

@@ -177,11 +177,21 @@ __global__ __launch_bounds__(64, 1) void k_dynamics_coop(const DynModel *__restr
         const int di = did[k];
         if (jty[k] == DJ_SPHERICAL) {
             jq[k] = qexp(mk(dp[di], dp[di + 1], dp[di + 2]));
-            tq[k] = qexp(mk(clampf(ac[di], M.act_lo[di], M.act_hi[di]), clampf(ac[di + 1], M.act_lo[di + 1], M.act_hi[di + 1]),
-                            clampf(ac[di + 2], M.act_lo[di + 2], M.act_hi[di + 2])));
             qd[k] = mk(dv[di], dv[di + 1], dv[di + 2]);
+            if (Mg.ctrl == PARC_CTRL_PD) {
+                tq[k] = qexp(mk(clampf(ac[di], M.act_lo[di], M.act_hi[di]), clampf(ac[di + 1], M.act_lo[di + 1], M.act_hi[di + 1]),
+                                clampf(ac[di + 2], M.act_lo[di + 2], M.act_hi[di + 2])));
+            } else { // the other control modes keep the joint's feed-forward torque (ctrl_ff) where the pd mode keeps its target
+                v3 diff = mk(0.f, 0.f, 0.f);
+                if (Mg.ctrl >= PARC_CTRL_PD_EXP) diff = qlog(qmul(qconj(jq[k]), qexp(mk(ac[di], ac[di + 1], ac[di + 2]))));
+                tq[k].x = ctrl_ff(Mg.ctrl, M.kp[di], M.kd[di], M.eff[di], M.act_lo[di], M.act_hi[di], ac[di], diff.x, qd[k].x);
+                tq[k].y = ctrl_ff(Mg.ctrl, M.kp[di + 1], M.kd[di + 1], M.eff[di + 1], M.act_lo[di + 1], M.act_hi[di + 1], ac[di + 1], diff.y, qd[k].y);
+                tq[k].z = ctrl_ff(Mg.ctrl, M.kp[di + 2], M.kd[di + 2], M.eff[di + 2], M.act_lo[di + 2], M.act_hi[di + 2], ac[di + 2], diff.z, qd[k].z);
+            }
         } else if (jty[k] == DJ_HINGE) {
-            hang[k] = dp[di]; thang[k] = clampf(ac[di], M.act_lo[di], M.act_hi[di]); qd[k].x = dv[di];
+            hang[k] = dp[di]; qd[k].x = dv[di];
+            if (Mg.ctrl == PARC_CTRL_PD) thang[k] = clampf(ac[di], M.act_lo[di], M.act_hi[di]);
+            else thang[k] = ctrl_ff(Mg.ctrl, M.kp[di], M.kd[di], M.eff[di], M.act_lo[di], M.act_hi[di], ac[di], ctrl_hinge_diff(Mg.ctrl, ac[di], hang[k]), qd[k].x);
         }
     }
     // root state lives in the lane of chain 0
@@ -419,7 +429,8 @@ __global__ __launch_bounds__(64, 1) void k_dynamics_coop(const DynModel *__restr
                                 if (nd == 3) {
                                     PARC_UNROLL
                                     for (int q = 0; q < 3; ++q) { const v3 a = mk(R.m[0][q], R.m[1][q], R.m[2][q]); Sc[q] = s6mk(a, cross(r, a)); }
-                                    const v3 err = qlog(qmul(qconj(jqk), tqk));
+                                    const bool pd = Mg.ctrl == PARC_CTRL_PD;
+                                    const v3 err = pd ? qlog(qmul(qconj(jqk), tqk)) : mk(tqk.x, tqk.y, tqk.z); // (not pd: the feed-forward torque)
                                     const v3 cur = qlog(jqk);
                                     const float e3[3] = {err.x, err.y, err.z}, c3[3] = {cur.x, cur.y, cur.z}, q3[3] = {qdk.x, qdk.y, qdk.z};
                                     PARC_UNROLL
@@ -427,6 +438,7 @@ __global__ __launch_bounds__(64, 1) void k_dynamics_coop(const DynModel *__restr
                                         float t = M.kp[di + q] * e3[q] - (M.kd[di + q] + dt * M.kp[di + q]) * q3[q];
                                         t = clampf(t, -M.eff[di + q], M.eff[di + q]);
                                         aug[q] = M.arm[di + q] + dt * M.kd[di + q] + dt * dt * M.kp[di + q];
+                                        if (!pd) drive_ff(Mg.ctrl, M.kd[di + q], M.arm[di + q], M.eff[di + q], dt, e3[q], q3[q], t, aug[q]);
                                         if (c3[q] < M.lo[di + q]) { t += Mg.lim_k * (M.lo[di + q] - c3[q]) - Mg.lim_d * q3[q]; aug[q] += dt * Mg.lim_d + dt * dt * Mg.lim_k; }
                                         else if (c3[q] > M.hi[di + q]) { t += Mg.lim_k * (M.hi[di + q] - c3[q]) - Mg.lim_d * q3[q]; aug[q] += dt * Mg.lim_d + dt * dt * Mg.lim_k; }
                                         tau[q] = t;
@@ -437,6 +449,7 @@ __global__ __launch_bounds__(64, 1) void k_dynamics_coop(const DynModel *__restr
                                     float t = M.kp[di] * (thk - hk) - (M.kd[di] + dt * M.kp[di]) * qdk.x;
                                     t = clampf(t, -M.eff[di], M.eff[di]);
                                     aug[0] = M.arm[di] + dt * M.kd[di] + dt * dt * M.kp[di];
+                                    if (Mg.ctrl != PARC_CTRL_PD) drive_ff(Mg.ctrl, M.kd[di], M.arm[di], M.eff[di], dt, thk, qdk.x, t, aug[0]);
                                     if (hk < M.lo[di]) { t += Mg.lim_k * (M.lo[di] - hk) - Mg.lim_d * qdk.x; aug[0] += dt * Mg.lim_d + dt * dt * Mg.lim_k; }
                                     else if (hk > M.hi[di]) { t += Mg.lim_k * (M.hi[di] - hk) - Mg.lim_d * qdk.x; aug[0] += dt * Mg.lim_d + dt * dt * Mg.lim_k; }
                                     tau[0] = t;

@@ -313,17 +313,28 @@ struct WvBody { // per-body registers of the owning lane
     v3 fcon_c;                           // contact force on the fixed leaf merged into this body (WvBodyC::child)
 };
 
+template <bool FF> // FF: a control mode other than pd -- B.tq.xyz / B.thang then hold the joint's feed-forward torque (ctrl_ff) instead of the target
 __device__ __forceinline__ void wv_load_joint(const DynModel &M, const WaveTables &W, int b, WvBody &B, const float *dp, const float *dv, const float *ac) {
     B.jq.x = 0.f; B.jq.y = 0.f; B.jq.z = 0.f; B.jq.w = 1.f; B.tq = B.jq; B.hang = 0.f; B.thang = 0.f; B.qd = mk(0.f, 0.f, 0.f);
     B.fcon = mk(0.f, 0.f, 0.f); B.qdd = mk(0.f, 0.f, 0.f); B.fcon_c = mk(0.f, 0.f, 0.f);
     const int jt = W.c[b].jtype, di = W.c[b].dof_idx;
     if (jt == DJ_SPHERICAL) {
         B.jq = qexp(mk(dp[di], dp[di + 1], dp[di + 2]));
-        B.tq = qexp(mk(clampf(ac[di], W.c[b].act_lo[0], W.c[b].act_hi[0]), clampf(ac[di + 1], W.c[b].act_lo[1], W.c[b].act_hi[1]),
-                       clampf(ac[di + 2], W.c[b].act_lo[2], W.c[b].act_hi[2])));
         B.qd = mk(dv[di], dv[di + 1], dv[di + 2]);
+        if (!FF) {
+            B.tq = qexp(mk(clampf(ac[di], W.c[b].act_lo[0], W.c[b].act_hi[0]), clampf(ac[di + 1], W.c[b].act_lo[1], W.c[b].act_hi[1]),
+                           clampf(ac[di + 2], W.c[b].act_lo[2], W.c[b].act_hi[2])));
+        } else {
+            v3 diff = mk(0.f, 0.f, 0.f);
+            if (M.ctrl >= PARC_CTRL_PD_EXP) diff = qlog(qmul(qconj(B.jq), qexp(mk(ac[di], ac[di + 1], ac[di + 2]))));
+            B.tq.x = ctrl_ff(M.ctrl, W.c[b].kp[0], W.c[b].kd[0], W.c[b].eff[0], W.c[b].act_lo[0], W.c[b].act_hi[0], ac[di], diff.x, B.qd.x);
+            B.tq.y = ctrl_ff(M.ctrl, W.c[b].kp[1], W.c[b].kd[1], W.c[b].eff[1], W.c[b].act_lo[1], W.c[b].act_hi[1], ac[di + 1], diff.y, B.qd.y);
+            B.tq.z = ctrl_ff(M.ctrl, W.c[b].kp[2], W.c[b].kd[2], W.c[b].eff[2], W.c[b].act_lo[2], W.c[b].act_hi[2], ac[di + 2], diff.z, B.qd.z);
+        }
     } else if (jt == DJ_HINGE) {
-        B.hang = dp[di]; B.thang = clampf(ac[di], W.c[b].act_lo[0], W.c[b].act_hi[0]); B.qd.x = dv[di];
+        B.hang = dp[di]; B.qd.x = dv[di];
+        if (!FF) B.thang = clampf(ac[di], W.c[b].act_lo[0], W.c[b].act_hi[0]);
+        else B.thang = ctrl_ff(M.ctrl, W.c[b].kp[0], W.c[b].kd[0], W.c[b].eff[0], W.c[b].act_lo[0], W.c[b].act_hi[0], ac[di], ctrl_hinge_diff(M.ctrl, ac[di], B.hang), B.qd.x);
     }
 }
 
@@ -672,7 +683,7 @@ __device__ __forceinline__ void wv_body_inertia(const DynModel &M, const WaveTab
 }
 
 // joint elimination of body b: (IA, pA) -> contribution (Ic, pc) to the parent; K and D^-1 u stay in `fac` (registers) for the outward pass
-template <int FS> // FS: stride of `fac` (1: a register array; 64: [slot][lane] in LDS)
+template <int FS, bool FF> // FS: stride of `fac` (1: a register array; 64: [slot][lane] in LDS); FF: see wv_load_joint
 __device__ __forceinline__ void wv_joint_inward(const DynModel &M, const WaveTables &W, int b, const WvBody &B, const m3 &R, float dt, const sym6 &IA, const s6 &pA,
                                                 sym6 &Ic, s6 &pc, float *fac) {
     const int jt = W.c[b].jtype, di = W.c[b].dof_idx;
@@ -685,14 +696,18 @@ __device__ __forceinline__ void wv_joint_inward(const DynModel &M, const WaveTab
         // U = U' R, D = R^T D' R, K = K' R, K u = K' u', I - K U^T = I - K' U'^T -- the same projection up to rounding).  The factors kept
         // for the outward pass are K' and D'^-1 u' (world axes); the joint-frame acceleration the integrator needs is R^T q'.
         float tau[3], aug[3];
-        const v3 err = qlog(qmul(qconj(B.jq), B.tq));
+        const v3 err = FF ? mk(B.tq.x, B.tq.y, B.tq.z) : qlog(qmul(qconj(B.jq), B.tq)); // (FF: the feed-forward torque)
         const v3 cur = qlog(B.jq);
         const float e3[3] = {err.x, err.y, err.z}, c3[3] = {cur.x, cur.y, cur.z}, q3[3] = {B.qd.x, B.qd.y, B.qd.z};
         PARC_UNROLL
         for (int q = 0; q < 3; ++q) {
-            float t = W.c[b].kp[q] * e3[q] - (W.c[b].kd[q] + dt * W.c[b].kp[q]) * q3[q];
-            t = clampf(t, -W.c[b].eff[q], W.c[b].eff[q]);
-            aug[q] = W.c[b].arm[q] + dt * W.c[b].kd[q] + dt * dt * W.c[b].kp[q];
+            float t, augq;
+            if (!FF) {
+                t = W.c[b].kp[q] * e3[q] - (W.c[b].kd[q] + dt * W.c[b].kp[q]) * q3[q];
+                t = clampf(t, -W.c[b].eff[q], W.c[b].eff[q]);
+                augq = W.c[b].arm[q] + dt * W.c[b].kd[q] + dt * dt * W.c[b].kp[q];
+            } else drive_ff(M.ctrl, W.c[b].kd[q], W.c[b].arm[q], W.c[b].eff[q], dt, e3[q], q3[q], t, augq);
+            aug[q] = augq;
             if (c3[q] < W.c[b].lo[q]) { t += M.lim_k * (W.c[b].lo[q] - c3[q]) - M.lim_d * q3[q]; aug[q] += dt * M.lim_d + dt * dt * M.lim_k; }
             else if (c3[q] > W.c[b].hi[q]) { t += M.lim_k * (W.c[b].hi[q] - c3[q]) - M.lim_d * q3[q]; aug[q] += dt * M.lim_d + dt * dt * M.lim_k; }
             tau[q] = t;
@@ -763,9 +778,12 @@ __device__ __forceinline__ void wv_joint_inward(const DynModel &M, const WaveTab
     } else if (jt == DJ_HINGE) {
         const v3 a = mulv(R, mk(W.c[b].axis[0], W.c[b].axis[1], W.c[b].axis[2]));
         const s6 Sc = s6mk(a, cross(r, a));
-        float t = W.c[b].kp[0] * (B.thang - B.hang) - (W.c[b].kd[0] + dt * W.c[b].kp[0]) * B.qd.x;
-        t = clampf(t, -W.c[b].eff[0], W.c[b].eff[0]);
-        float aug = W.c[b].arm[0] + dt * W.c[b].kd[0] + dt * dt * W.c[b].kp[0];
+        float t, aug;
+        if (!FF) {
+            t = W.c[b].kp[0] * (B.thang - B.hang) - (W.c[b].kd[0] + dt * W.c[b].kp[0]) * B.qd.x;
+            t = clampf(t, -W.c[b].eff[0], W.c[b].eff[0]);
+            aug = W.c[b].arm[0] + dt * W.c[b].kd[0] + dt * dt * W.c[b].kp[0];
+        } else drive_ff(M.ctrl, W.c[b].kd[0], W.c[b].arm[0], W.c[b].eff[0], dt, B.thang, B.qd.x, t, aug);
         if (B.hang < W.c[b].lo[0]) { t += M.lim_k * (W.c[b].lo[0] - B.hang) - M.lim_d * B.qd.x; aug += dt * M.lim_d + dt * dt * M.lim_k; }
         else if (B.hang > W.c[b].hi[0]) { t += M.lim_k * (W.c[b].hi[0] - B.hang) - M.lim_d * B.qd.x; aug += dt * M.lim_d + dt * dt * M.lim_k; }
         const s6 Uc = symmul(IA, Sc);
@@ -860,10 +878,11 @@ __device__ __forceinline__ void wv_store_joint(const DynModel &M, const WaveTabl
     }
 }
 
-__global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__restrict__ Mp, const WaveTables *__restrict__ Wp, DynTerrain T,
-                                                          ParcEnvBuffers buf, const float *__restrict__ action,
-                                                          const float *__restrict__ env_off_all, float *__restrict__ root_shadow,
-                                                          float4 *__restrict__ prep, float *__restrict__ man_g, int N, int epb) {
+template <bool FF> // the kernel's body; FF = a control mode other than pd (k_dynamics_wave_ff): an instantiation of its own, the default one carries none of it
+__device__ __forceinline__ void dynamics_wave_body(const DynModel *__restrict__ Mp, const WaveTables *__restrict__ Wp, DynTerrain T,
+                                                   ParcEnvBuffers buf, const float *__restrict__ action,
+                                                   const float *__restrict__ env_off_all, float *__restrict__ root_shadow,
+                                                   float4 *__restrict__ prep, float *__restrict__ man_g, int N, int epb) {
     extern __shared__ float smem[];
     const DynModel &M = *Mp;
     const WaveTables &W = *Wp;
@@ -952,8 +971,8 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
         // prologue's only dependent chain of global loads (root position + env origin -> cell -> heights)
         PARC_UNROLL
         for (int k = 0; k < WV_MAXLEN; ++k) {
-            if (k < llen) wv_load_joint(M, W, W.body[lc][k], limb[k], dp, dv, ac);
-            if (k < tlen) wv_load_joint(M, W, W.body[0][k], trunk[k], dp, dv, ac);
+            if (k < llen) wv_load_joint<FF>(M, W, W.body[lc][k], limb[k], dp, dv, ac);
+            if (k < tlen) wv_load_joint<FF>(M, W, W.body[0][k], trunk[k], dp, dv, ac);
         }
         PARC_UNROLL
         for (int it = 0; it < NP; ++it) {
@@ -1042,7 +1061,7 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
             sym6 IA = Icl; s6 pA = pcl;
             WSTAMP(15);
             wv_body_inertia(M, W, T, X, b, limb[k], R, rootp, IA, pA, man, 3 + k, discover WSTAMP_ARGS);
-            wv_joint_inward<1>(M, W, b, limb[k], R, dt, IA, pA, Icl, pcl, fac_l[k]);
+            wv_joint_inward<1, FF>(M, W, b, limb[k], R, dt, IA, pA, Icl, pcl, fac_l[k]);
             WPIN(Icl, pcl);
             WSTAMP(14);
         };
@@ -1174,7 +1193,7 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
                     PARC_UNROLL
                     for (int a = 0; a < 6; ++a) acc_root.a[a] = xs[a];
                 } else {
-                    wv_joint_inward<WV_TFS>(M, W, b, trunk[k], R, dt, IA, pA, Ict, pct, WV_TFAC(k));
+                    wv_joint_inward<WV_TFS, FF>(M, W, b, trunk[k], R, dt, IA, pA, Ict, pct, WV_TFAC(k));
                 }
             };
             PARC_UNROLL
@@ -1323,6 +1342,19 @@ __global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__rest
     WSTAMP(10);
     if (lane == 0) for (int i = 0; i < 16; ++i) atomicAdd(&g_wave_stamps[w][i], wacc[i]);
 #endif
+}
+__global__ __launch_bounds__(256, 1) void k_dynamics_wave(const DynModel *__restrict__ Mp, const WaveTables *__restrict__ Wp, DynTerrain T,
+                                                          ParcEnvBuffers buf, const float *__restrict__ action,
+                                                          const float *__restrict__ env_off_all, float *__restrict__ root_shadow,
+                                                          float4 *__restrict__ prep, float *__restrict__ man_g, int N, int epb) {
+    dynamics_wave_body<false>(Mp, Wp, T, buf, action, env_off_all, root_shadow, prep, man_g, N, epb);
+}
+// control modes vel / torque / pd_exp / pd_1d (DynModel::ctrl)
+__global__ __launch_bounds__(256, 1) void k_dynamics_wave_ff(const DynModel *__restrict__ Mp, const WaveTables *__restrict__ Wp, DynTerrain T,
+                                                             ParcEnvBuffers buf, const float *__restrict__ action,
+                                                             const float *__restrict__ env_off_all, float *__restrict__ root_shadow,
+                                                             float4 *__restrict__ prep, float *__restrict__ man_g, int N, int epb) {
+    dynamics_wave_body<true>(Mp, Wp, T, buf, action, env_off_all, root_shadow, prep, man_g, N, epb);
 }
 #endif // __HIPCC__
 

@@ -1804,6 +1804,16 @@ extern "C" int parc_env_create(const ParcEnvConfig *cfg, ParcEnv **out) {
             return fail(PARC_ERR_INVALID, "dynamics: " + std::to_string(t) + " collision point(s) / segment(s) / geom(s) do not fit the model tables (DYN_MAXC " +
                         std::to_string(DYN_MAXC) + ", DYN_MAXS " + std::to_string(DYN_MAXS) + ", " + std::to_string(PARC_MAX_GEOMS) + " geoms)");
         }
+        { // control mode (ig_char_env.py:21-26, 95)
+            const int cm = cfg->dynamics.control_mode;
+            bool all_1d = true;
+            for (int b = 1; b < cfg->model.num_bodies; ++b) all_1d = all_1d && cfg->model.joint_type[b] != parcdyn::DJ_SPHERICAL;
+            if (cm < PARC_CTRL_PD || cm > PARC_CTRL_PD_1D || (cm == PARC_CTRL_PD_1D && !all_1d)) {
+                free_dev(e); delete e;
+                return fail(PARC_ERR_INVALID, cm == PARC_CTRL_PD_1D ? "control_mode pd_1d only supports characters whose joints all have one dof (the reference asserts it, ig_char_env.py:246-250)"
+                                                                     : "unknown control_mode " + std::to_string(cm));
+            }
+        }
         // developer switches for ablation measurements (ParcEnvConfig::dev_options; the product never sets them)
         {
             const std::string mode = dev_opt(cfg, "segments"); // "none": collision points only; "capsules": drop the sole edges of boxes
@@ -1851,7 +1861,8 @@ extern "C" int parc_env_create(const ParcEnvConfig *cfg, ParcEnv **out) {
                 r = hipMalloc((void **)&e->d_man_ovf, sizeof(float) * (size_t)((N + epb - 1) / epb) * WV_MAXLIMB * WV_MAN_OVF * 8 * 64);
             }
             if (r == hipSuccess)
-                r = hipFuncSetAttribute((const void *)parcdyn::k_dynamics_wave, hipFuncAttributeMaxDynamicSharedMemorySize, parcdyn::wv_lds_floats() * (int)sizeof(float));
+                r = hipFuncSetAttribute(cfg->dynamics.control_mode == PARC_CTRL_PD ? (const void *)parcdyn::k_dynamics_wave : (const void *)parcdyn::k_dynamics_wave_ff,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, parcdyn::wv_lds_floats() * (int)sizeof(float));
         } else if (e->use_coop) {
             r = up((void **)&e->d_coop, &e->h_coop, sizeof(e->h_coop));
         }
@@ -2026,9 +2037,14 @@ static int launch_dynamics(ParcEnv *e, const float *action_dev, hipStream_t st) 
     T.hf = e->d_hf; T.X = e->sp.X; T.Y = e->sp.Y; T.min_x = e->sp.min_x; T.min_y = e->sp.min_y; T.dx = e->sp.dx; T.dy = e->sp.dy;
     if (e->use_wave) {
         const int epb = wave_envs_per_block(e->N, e->num_cus);
-        hipLaunchKernelGGL(parcdyn::k_dynamics_wave, dim3((e->N + epb - 1) / epb), dim3(256), parcdyn::wv_lds_floats() * sizeof(float), st,
-                           (const parcdyn::DynModel *)e->d_dyn, (const parcdyn::WaveTables *)e->d_wave, T, e->sp.buf, action_dev,
-                           (const float *)e->d_env_off, e->d_root_shadow, e->d_prep, e->d_man_ovf, e->N, epb);
+        if (e->cfg.dynamics.control_mode == PARC_CTRL_PD)
+            hipLaunchKernelGGL(parcdyn::k_dynamics_wave, dim3((e->N + epb - 1) / epb), dim3(256), parcdyn::wv_lds_floats() * sizeof(float), st,
+                               (const parcdyn::DynModel *)e->d_dyn, (const parcdyn::WaveTables *)e->d_wave, T, e->sp.buf, action_dev,
+                               (const float *)e->d_env_off, e->d_root_shadow, e->d_prep, e->d_man_ovf, e->N, epb);
+        else // control modes vel / torque / pd_exp / pd_1d: the instantiation with the feed-forward joint torques
+            hipLaunchKernelGGL(parcdyn::k_dynamics_wave_ff, dim3((e->N + epb - 1) / epb), dim3(256), parcdyn::wv_lds_floats() * sizeof(float), st,
+                               (const parcdyn::DynModel *)e->d_dyn, (const parcdyn::WaveTables *)e->d_wave, T, e->sp.buf, action_dev,
+                               (const float *)e->d_env_off, e->d_root_shadow, e->d_prep, e->d_man_ovf, e->N, epb);
     }
     else if (e->use_coop)
         hipLaunchKernelGGL(parcdyn::k_dynamics_coop, dim3((e->N + CO_ENVS - 1) / CO_ENVS), dim3(64), 0, st, (const parcdyn::DynModel *)e->d_dyn,
@@ -2642,10 +2658,13 @@ extern "C" const char *parc_env_describe(ParcEnv *e) {
     if (!e) return "";
     char b[1024];
     std::string d;
-    const char *dk = !e->cfg.enable_dynamics ? "none" : (e->use_wave ? "k_dynamics_wave" : (e->use_coop ? "k_dynamics_coop" : "k_dynamics"));
+    const bool ctrl_ff = e->cfg.enable_dynamics && e->cfg.dynamics.control_mode != PARC_CTRL_PD;
+    const char *dk = !e->cfg.enable_dynamics ? "none" : (e->use_wave ? (ctrl_ff ? "k_dynamics_wave_ff" : "k_dynamics_wave") : (e->use_coop ? "k_dynamics_coop" : "k_dynamics"));
     snprintf(b, sizeof(b), "dynamics_kernel=%s;", dk); d += b;
     if (e->cfg.enable_dynamics) {
         const parcdyn::DynModel &m = e->h_dyn;
+        static const char *const ctrl_names[] = {"pd", "vel", "torque", "pd_exp", "pd_1d"};
+        snprintf(b, sizeof(b), "control_mode=%s;", ctrl_names[m.ctrl]); d += b;
         snprintf(b, sizeof(b), "envs_per_block=%d;substeps=%d;substep_dt=%.9g;collision_points=%d;collision_segments=%d;kn=%g;dn=%g;dtang=%g;mu=%g;pen_cap=%g;"
                  "manifold_period=%d;spec_m0=%g;spec_tv=%g;spec_max=%g;root_residual=%d;", e->use_wave ? wave_envs_per_block(e->N, e->num_cus) : (e->use_coop ? CO_ENVS : 64),
                  m.nsub, (double)m.dt, m.ncol, m.nseg, (double)m.kn, (double)m.dn, (double)m.dtang, (double)m.mu, (double)m.pen_cap, m.man_period, (double)m.spec_m0,

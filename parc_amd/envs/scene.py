@@ -59,6 +59,20 @@ def build_action_bounds_pd(cm: CharModel):
     return low, high
 
 
+CONTROL_MODES = {"pd": 0, "vel": 1, "torque": 2, "pd_exp": 3, "pd_1d": 4}   # ig_char_env.py:21-26 = PARC_CTRL_* of include/parc_env.h
+
+
+def build_action_bounds(cm: CharModel, control_mode: str):
+    """ig_char_env.py:252-268: pd / pd_exp / pd_1d -> the pd bounds, vel -> +-2 pi (:349-353), torque -> +- the motor efforts (:355-362)."""
+    if control_mode == "vel":
+        n = cm.get_dof_size()
+        return -2.0 * np.pi * np.ones([n]), 2.0 * np.pi * np.ones([n])
+    if control_mode == "torque":
+        eff = np.asarray(cm.dof_pd_params()[3], np.float64)
+        return -eff, eff
+    return build_action_bounds_pd(cm)
+
+
 def env_offsets_square(num_envs, env_spacing, env_id_base=0, total_envs=None):
     """ig_parkour_env.py:386-398 for the global env ids [base, base + num_envs)."""
     total = num_envs if total_envs is None else total_envs
@@ -115,6 +129,7 @@ def fill_dynamics(dp: L.ParcDynamicsParams, cm: CharModel, env_config: dict, sim
     dp.restitution = 0.0
     dp.contact_offset = physx.get("contact_offset", 0.02)
     dp.max_depenetration_velocity = physx.get("max_depenetration_velocity", 10.0)
+    dp.control_mode = CONTROL_MODES[env_config.get("control_mode", "pd")]
     dp.angular_damping = 0.01
     dp.max_angular_velocity = 100.0
 
@@ -157,8 +172,9 @@ def build_scene(config: dict, num_envs: int, device_index: int = 0, env_id_base:
     _ = env_config["contact_detection_eps"]  # read but unused by the reference too (ig_parkour_env.py:55,655)
     use_contact_info = bool(env_config["use_contact_info"])      # ig_parkour_env.py:72
     enable_tar_obs = bool(env_config.get("enable_tar_obs", True))  # :83
-    if env_config.get("control_mode", "pd") != "pd":
-        raise ValueError("only control_mode: pd is supported")
+    control_mode = env_config.get("control_mode", "pd")                # ig_char_env.py:95 (ControlMode[...])
+    if control_mode not in CONTROL_MODES:
+        raise KeyError(control_mode)
     _ = env_config["debug_visuals"], env_config["ref_char_offset"], env_config["camera_mode"]
 
     char_file = str(path_loader.resolve_path(env_config["char_file"]))
@@ -177,7 +193,10 @@ def build_scene(config: dict, num_envs: int, device_index: int = 0, env_id_base:
     if env_offsets is not None:  # test hook: env origins given by the caller (the far-origin parity fixture) instead of the square layout
         env_off = np.ascontiguousarray(env_offsets, np.float32)
         assert env_off.shape == (num_envs, 3)
-    act_low, act_high = build_action_bounds_pd(cm)
+    if control_mode == "pd_1d":  # the reference's assert (ig_char_env.py:246-250)
+        for j in range(1, cm.get_num_joints()):
+            assert cm.get_joint_dof_dim(j) == 1, "pd_1d only supports 1D joints"
+    act_low, act_high = build_action_bounds(cm, control_mode)
     jw, dw = parse_joint_err_weights(cm, env_config.get("joint_err_w", None))
 
     # ---- motions + terrain -------------------------------------------------------------------------

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # PARC_ENV_LIB: developer override used to A/B kernel builds; the shipped library is the in-tree one
 LIB_PATH = os.environ.get("PARC_ENV_LIB") or os.path.join(_HERE, "libparc_env.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_BODIES, MAX_DOFS, MAX_TAR_STEPS, MAX_KEY, MAX_FK_PATHS, MAX_FK_DEPTH, MAX_GEOMS = 16, 40, 6, 8, 8, 8, 24
 
 f32p = C.POINTER(C.c_float)
@@ -39,7 +39,7 @@ class ParcDynamicsParams(C.Structure):
                 ("gravity_z", C.c_float), ("sim_dt", C.c_float), ("sim_steps", C.c_int32), ("substeps", C.c_int32),
                 ("solver_iterations", C.c_int32), ("friction", C.c_float), ("restitution", C.c_float),
                 ("contact_offset", C.c_float), ("max_depenetration_velocity", C.c_float),
-                ("angular_damping", C.c_float), ("max_angular_velocity", C.c_float)]
+                ("angular_damping", C.c_float), ("max_angular_velocity", C.c_float), ("control_mode", C.c_int32)]
 
 
 class ParcEnvConfig(C.Structure):

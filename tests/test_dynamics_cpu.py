@@ -579,3 +579,76 @@ def test_contact_manifold_speculative_planes_and_cached_planes(dyn):
     left4, left1 = int(np.argmax(z4 < 1.0)), int(np.argmax(z1 < 1.0))       # first control step at which the box centre is below the platform top
     assert left1 > 5 and 0 <= left4 - left1 <= 1, (left4, left1)           # carried at most one control step longer
     assert abs(z4[-1] - z1[-1]) < 0.25 * abs(1.0 - z1[-1]) + 0.02, (z4[-1], z1[-1])    # then it falls the same way
+
+
+def _dyn_with_control_mode(mode):
+    from oracle.binding_dyn import DynOracle
+    from parc_amd.envs import scene
+    from parc_amd.util import path_loader
+    cfg = path_loader.load_config(os.path.join(DATA, "configs/tracker_config/dm_env_default.yaml"))
+    cfg["env"]["control_mode"] = mode
+    sc = scene.build_scene(cfg, 4, verbose=False)
+    return DynOracle(sc.cfg), sc
+
+
+def test_control_modes_vel_torque_pd_exp(dyn, oracle, orc_char):
+    """The reference's other control modes (ig_char_env.py:21-26).  No PhysX answer exists for them either (parity unpinned):
+    what each mode MEANS is checked -- torque: the clipped action is the joint torque, nothing else drives the joint; vel: the joint's rate goes to
+    the clipped action at the rate damping / inertia; pd_exp: the explicit PD torque of the step's first state, target = the action as given,
+    limited to the motor efforts, which for soft gains follows the implicit pd drive."""
+    n = 2
+    off = np.zeros((n, 3), np.float32)
+    # ---- torque, zero action = the pd mode without gains: a limp character, bit for bit the same trajectory
+    d_tq, sc_tq = _dyn_with_control_mode("torque")
+    d_pd, _ = _dyn_with_control_mode("pd")
+    d_pd.scale_gains(0.0)
+    rng = np.random.default_rng(5)
+    st_a = make_state(n, z=1.2); st_a["dof_pos"][:] = 0.2 * rng.standard_normal((n, 28)).astype(np.float32)
+    st_b = {k: v.copy() for k, v in st_a.items()}
+    for _ in range(20):
+        d_tq.step(*FLAT, st_a, np.zeros((n, 28), np.float32), off)
+        d_pd.step(*FLAT, st_b, st_b["dof_pos"].copy(), off)
+    assert np.abs(st_a["contact_force"]).max() > 0   # it has fallen onto the ground by then
+    for k in ("root_pos", "root_rot", "dof_pos", "dof_vel", "contact_force"):
+        assert np.array_equal(st_a[k], st_b[k]), k
+    # ---- torque: a constant elbow torque in free flight, no gravity: the elbow's rate grows by torque / (effective inertia) per second; the torque is
+    # the action clipped to +- the motor effort (70 N m for the elbow, humanoid.xml), and the internal torque leaves the angular momentum alone
+    d_tq.set_gravity(0.0)
+    eff = sc_tq.action_high.astype(np.float32)
+    assert eff[9] == 70.0 and np.array_equal(sc_tq.action_low, -sc_tq.action_high)
+    rates, finals = [], []
+    for a in (0.5, 1.0, 70.0, 1000.0):
+        st = make_state(n, z=50.0)
+        act = np.zeros((n, 28), np.float32); act[:, 9] = a
+        d_tq.step(*FLAT, st, act, off)
+        rates.append(float(st["dof_vel"][0, 9])); finals.append(st)
+        assert np.abs(st["root_ang_vel"]).max() > 0 and np.all(np.isfinite(st["dof_vel"]))
+    assert rates[0] > 0.1 and abs(rates[1] / rates[0] - 2.0) < 0.01, rates                            # linear in the torque ...
+    assert all(np.array_equal(finals[2][k], finals[3][k]) for k in ("dof_pos", "dof_vel", "root_ang_vel"))  # ... up to the motor effort: 1000 N m acts as 70
+    # ---- vel: the joint rates settle on the clipped action
+    d_v, sc_v = _dyn_with_control_mode("vel")
+    d_v.set_gravity(0.0)
+    assert np.allclose(sc_v.action_high, 2 * np.pi)
+    st = make_state(n, z=50.0)
+    act = np.zeros((n, 28), np.float32); act[:, 9] = 1.5; act[:, 13] = -100.0    # elbows: 1.5 rad/s; -100 clips to -2 pi
+    act[:, 24] = 0.5                                                              # a knee
+    for _ in range(4):
+        d_v.step(*FLAT, st, act, off)
+    assert abs(st["dof_vel"][0, 9] - 1.5) < 0.05 and abs(st["dof_vel"][0, 13] + 2 * np.pi) < 0.2 and abs(st["dof_vel"][0, 24] - 0.5) < 0.05, st["dof_vel"][0, [9, 13, 24]]
+    # ---- pd_exp: with gains small enough for an explicit torque held over a control step, it tracks the implicit pd drive; the target is NOT clipped
+    d_e, sc_e = _dyn_with_control_mode("pd_exp")
+    d_i, _ = _dyn_with_control_mode("pd")
+    for dd in (d_e, d_i):
+        dd.set_gravity(0.0); dd.scale_gains(0.02)
+    tgt = np.zeros((n, 28), np.float32); tgt[:, 9] = 0.8; tgt[:, 17] = 0.6; tgt[:, 0:3] = [0.2, -0.1, 0.15]; tgt[:, 3:6] = [0.0, 0.3, 0.0]
+    st_e = make_state(n, z=50.0); st_i = make_state(n, z=50.0)
+    for _ in range(10):
+        d_e.step(*FLAT, st_e, tgt, off); d_i.step(*FLAT, st_i, tgt, off)
+    moved = np.abs(st_i["dof_pos"]).max()
+    assert moved > 0.05 and np.abs(st_e["dof_pos"] - st_i["dof_pos"]).max() < 0.12 * moved, (moved, np.abs(st_e["dof_pos"] - st_i["dof_pos"]).max())
+    big = tgt.copy(); big[:, 9] = 50.0        # far outside the pd bounds: pd clips it to 2.52 rad, pd_exp goes the shorter way round to 50 rad (mod 2 pi)
+    st_e = make_state(n, z=50.0); st_i = make_state(n, z=50.0)
+    st_e["dof_pos"][:, 9] = 1.0; st_i["dof_pos"][:, 9] = 1.0   # (mid range: the joint limit stays out of it)
+    d_e.step(*FLAT, st_e, big, off); d_i.step(*FLAT, st_i, big, off)
+    want = 49.0 - 2 * np.pi * np.round(49.0 / (2 * np.pi))    # -1.265 rad: the elbow is driven the other way
+    assert want < 0 and st_e["dof_vel"][0, 9] < -0.05 and st_i["dof_vel"][0, 9] > 0.05, (st_e["dof_vel"][0, 9], st_i["dof_vel"][0, 9])

@@ -68,7 +68,7 @@ def test_library_loaded_is_in_tree(genv):
     from parc_amd import lib as L
     assert L.LIB_PATH.endswith("parc_amd/libparc_env.so")
     from parc_amd import lib as L2
-    assert genv[0]._lib.parc_abi_version() == L2.ABI_VERSION == 5
+    assert genv[0]._lib.parc_abi_version() == L2.ABI_VERSION == 6
 
 
 def test_kin_ops_vs_golden(genv):

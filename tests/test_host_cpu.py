@@ -119,8 +119,22 @@ def test_scene_assembly_and_action_bounds():
     cfg["env"]["enable_tar_obs"] = False
     sc3 = scene.build_scene(cfg, 4, verbose=False)
     assert sc3.cfg.enable_tar_obs == 0 and list(sc3.obs_shapes) == ["char_obs", "hf"] and sum(int(np.prod(v["shape"])) for v in sc3.obs_shapes.values()) == 136 + 441
-    cfg = default_config(); cfg["env"]["control_mode"] = "vel"               # the other control modes stay rejected
-    with pytest.raises(ValueError):
+    # control modes (ig_char_env.py:21-26, 252-268, 349-362): built since round 4 -- their action bounds here, their dynamics in test_dynamics_*
+    cfg = default_config(); cfg["env"]["control_mode"] = "vel"
+    sv = scene.build_scene(cfg, 4, verbose=False)
+    assert sv.cfg.dynamics.control_mode == 1 and np.allclose(sv.action_low, -2 * np.pi) and np.allclose(sv.action_high, 2 * np.pi)
+    cfg["env"]["control_mode"] = "torque"
+    st = scene.build_scene(cfg, 4, verbose=False)
+    eff = np.array([st.cfg.dynamics.dof_effort[d] for d in range(len(st.action_low))])
+    assert st.cfg.dynamics.control_mode == 2 and eff.min() > 0 and np.allclose(st.action_high, eff) and np.allclose(st.action_low, -eff)
+    cfg["env"]["control_mode"] = "pd_exp"
+    se = scene.build_scene(cfg, 4, verbose=False)
+    assert se.cfg.dynamics.control_mode == 3 and np.array_equal(se.action_low, sc.action_low) and np.array_equal(se.action_high, sc.action_high)
+    cfg["env"]["control_mode"] = "pd_1d"                                     # the humanoid has spherical joints: the reference asserts (:246-250)
+    with pytest.raises(AssertionError):
+        scene.build_scene(cfg, 4, verbose=False)
+    cfg["env"]["control_mode"] = "pid"
+    with pytest.raises(KeyError):                                           # ControlMode["pid"]
         scene.build_scene(cfg, 4, verbose=False)
     # developer switches travel in the config (ParcEnvConfig.dev_options), the library reads no environment variable
     assert scene.format_dev_options(None) is None and scene.format_dev_options({"kernel": "wave"}) is None
@@ -323,8 +337,9 @@ def test_dynamics_kernel_of_the_built_library_uses_no_scratch(tmp_path):
         if m:
             kern[m.group(1)] = {k: int(v) for k, v in re.findall(r"\.(private_segment_fixed_size|vgpr_count|sgpr_count|group_segment_fixed_size):\s+(\d+)", blk)}
     wave = [v for k, v in kern.items() if "k_dynamics_wave" in k]
-    assert len(wave) == 1, list(kern)
-    assert wave[0]["private_segment_fixed_size"] == 0, wave[0]
-    assert wave[0]["vgpr_count"] > 256, wave[0]        # VGPRs + AGPRs of the one resident wave per SIMD
+    assert len(wave) == 2, list(kern)                   # the pd instantiation and k_dynamics_wave_ff (the other control modes)
+    for wk in wave:
+        assert wk["private_segment_fixed_size"] == 0, wk
+        assert wk["vgpr_count"] > 256, wk               # VGPRs + AGPRs of the one resident wave per SIMD
     post = [v for k, v in kern.items() if "k_env_post" in k]
     assert len(post) == 9 and all(p["vgpr_count"] <= 102 for p in post), post   # (STEP, OBS) x MIRROR, the two track_root=false STEP instantiations, three with global_obs; 5 waves per SIMD need <= 102 registers
