@@ -246,6 +246,9 @@ int parc_env_get_motion_info(ParcEnv *env, float *lengths_host, float *weights_h
 /* `never_done` (ig_parkour_env.py:59,980): done flags read NULL after update_done, so the agent resets nothing and
  * parc_env_reset_done resets nobody; the fail-rate curriculum still sees the episode ends, as in the reference. */
 int parc_env_set_never_done(ParcEnv *env, int32_t never_done);
+/* reset sampling switches of DeepMimicEnv: `rand_reset` / `demo_mode` (dm_env.py:28-29,479-505; set_demo_mode :737-741) and the scale of the random
+ * root offset; the per-env start time as a fraction of the clip length used when rand_reset is off (set_motion_start_time_fraction, dm_env.py:743-744,
+ * read at :502; the record mode's retry schedule sets it) */
 int parc_env_set_rand_reset(ParcEnv *env, int32_t rand_reset, int32_t demo_mode, float root_pos_offset_scale);
 int parc_env_set_start_time_fraction(ParcEnv *env, const float *frac_dev /* [N] or NULL */);
 
