@@ -652,3 +652,70 @@ def test_control_modes_vel_torque_pd_exp(dyn, oracle, orc_char):
     d_e.step(*FLAT, st_e, big, off); d_i.step(*FLAT, st_i, big, off)
     want = 49.0 - 2 * np.pi * np.round(49.0 / (2 * np.pi))    # -1.265 rad: the elbow is driven the other way
     assert want < 0 and st_e["dof_vel"][0, 9] < -0.05 and st_i["dof_vel"][0, 9] > 0.05, (st_e["dof_vel"][0, 9], st_i["dof_vel"][0, 9])
+
+
+def _hinge_chain(sc, control_mode):
+    """DynOracle of a three-link chain with two hinge joints (about y), free-floating base: the smallest character pd_1d accepts."""
+    from oracle.binding_dyn import DynOracle
+    from parc_amd import lib as L
+    from parc_amd.envs import scene
+    cfg = L.ParcEnvConfig.from_buffer_copy(bytes(sc.cfg))
+    m = cfg.model
+    m.num_bodies = 3; m.dof_size = 2
+    for b, (par, jt, di) in enumerate([(-1, 0, 0), (0, 1, 0), (1, 1, 1)]):   # joint types of parc_dynamics.hpp: 0 root, 1 hinge
+        m.parent[b] = par; m.joint_type[b] = jt; m.dof_idx[b] = di
+        for a in range(3):
+            m.local_translation[b][a] = [0.0, 0.0, -0.4][a] if b > 0 else 0.0
+            m.joint_axis[b][a] = [0.0, 1.0, 0.0][a]
+        for a in range(4):
+            m.local_rotation[b][a] = [0.0, 0.0, 0.0, 1.0][a]
+    dp = cfg.dynamics
+    dp.num_geoms = 3
+    for g in range(3):   # a capsule along -z per link
+        dp.geom_body[g] = g; dp.geom_type[g] = 2; dp.geom_density[g] = 1000.0
+        for a in range(3):
+            dp.geom_pos[g][a] = 0.0; dp.geom_pos2[g][a] = [0.0, 0.0, -0.35][a]; dp.geom_size[g][a] = [0.05, 0.0, 0.0][a]
+    for d in range(2):
+        dp.dof_stiffness[d] = 60.0; dp.dof_damping[d] = 6.0; dp.dof_armature[d] = 0.01; dp.dof_effort[d] = 40.0
+        dp.dof_lower[d] = -3.0; dp.dof_upper[d] = 3.0
+        cfg.action_low[d] = -40.0 if control_mode == "torque" else -4.0
+        cfg.action_high[d] = 40.0 if control_mode == "torque" else 4.0
+    dp.control_mode = scene.CONTROL_MODES[control_mode]
+    return DynOracle(cfg)
+
+
+def _chain_state(n, q, qd):
+    st = dict(root_pos=np.zeros((n, 3), np.float32), root_rot=np.zeros((n, 4), np.float32), root_vel=np.zeros((n, 3), np.float32),
+              root_ang_vel=np.zeros((n, 3), np.float32), dof_pos=np.tile(np.asarray(q, np.float32), (n, 1)), dof_vel=np.tile(np.asarray(qd, np.float32), (n, 1)),
+              contact_force=np.zeros((n, 3, 3), np.float32))
+    st["root_rot"][:, 3] = 1.0; st["root_pos"][:, 2] = 50.0
+    return st
+
+
+def test_control_mode_pd_1d_on_a_hinge_chain(dyn):
+    """pd_1d (ig_char_env.py:411-421, asserted to be a character of 1-dof joints :246-250): torque = kp (target - dof) - kd dof_vel from the state at
+    the start of the control step, limited to the motor effort, target = the action as given.  On a two-hinge chain: (1) the step equals the torque
+    mode's step with that torque as the action, bit for bit; (2) pd_exp differs from it exactly when the plain difference and the rotation
+    difference differ (|target - dof| > pi: pd_exp goes the shorter way round)."""
+    _, sc = dyn
+    n = 2
+    off = np.zeros((n, 3), np.float32)
+    d1, dt_, de = _hinge_chain(sc, "pd_1d"), _hinge_chain(sc, "torque"), _hinge_chain(sc, "pd_exp")
+    for d in (d1, dt_, de):
+        d.set_gravity(0.0)
+    q0, qd0 = [0.3, -0.2], [0.5, -1.0]
+    for tgt in ([0.8, -0.6], [2.5, 1.0], [9.0, -0.2]):        # the last one: out of the bounds a pd target would be clipped to, and 8.7 rad away
+        a = np.tile(np.asarray(tgt, np.float32), (n, 1))
+        s1, s2, s3 = _chain_state(n, q0, qd0), _chain_state(n, q0, qd0), _chain_state(n, q0, qd0)
+        tau = np.clip(np.float32(60.0) * (a - s1["dof_pos"]) - np.float32(6.0) * s1["dof_vel"], -40.0, 40.0).astype(np.float32)
+        d1.step(*FLAT, s1, a, off); dt_.step(*FLAT, s2, tau, off); de.step(*FLAT, s3, a, off)
+        assert np.all(np.isfinite(s1["dof_vel"])) and np.abs(s1["dof_vel"] - np.asarray(qd0, np.float32)).max() > 0.05
+        for k in ("dof_pos", "dof_vel", "root_pos", "root_rot", "root_vel", "root_ang_vel"):
+            assert np.array_equal(s1[k], s2[k]), (tgt, k)                              # (1)
+        if abs(tgt[0] - q0[0]) <= np.pi:                                               # (2) within half a turn the two differences coincide ...
+            assert np.array_equal(s1["dof_vel"], s3["dof_vel"]), tgt
+    # ... (9.0 - 0.3 = 2 pi + 2.42 rad also gives the same step: both torques sit at the motor limit, on the same side) ... and beyond it they part:
+    s_a, s_b = _chain_state(n, q0, qd0), _chain_state(n, q0, qd0)
+    far = np.tile(np.asarray([0.3 + 4.0, -0.2], np.float32), (n, 1))                  # 4.0 rad ahead = 2.28 rad behind, the shorter way
+    d1.step(*FLAT, s_a, far, off); de.step(*FLAT, s_b, far, off)
+    assert s_a["dof_vel"][0, 0] > qd0[0] and s_b["dof_vel"][0, 0] < qd0[0], (s_a["dof_vel"][0], s_b["dof_vel"][0])
