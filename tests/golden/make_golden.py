@@ -617,6 +617,41 @@ def gen_env_step_local_root(m):
     print("local-root fixture: done histogram", np.bincount(npy(env._done_buf), minlength=4), "reward range", float(env._reward_buf.min()), float(env._reward_buf.max()))
 
 
+def gen_env_step_reward_done_switches(m):
+    """`track_root_h: False` (compute_deepmimic_reward: the vertical root error leaves the root-position term, mgdm_dm_util.py) and
+    `enable_early_termination: False` (compute_done: only the time limit and the motion end finish an episode).  Two sub-fixtures on the state of
+    env_step_local_root (sixteen characters turned, sixteen displaced) with sixteen more rows lifted / lowered by up to 0.5 m, so that both switches
+    change what the default config would give: keys `h0_*` (track_root_h off) and `et0_*` (early termination off)."""
+    arrs = {}
+    for tag, key, val in (("h0_", "track_root_h", False), ("et0_", "enable_early_termination", False)):
+        cfg = env_config()
+        cfg["env"][key] = val
+        n = 64
+        env, dm = build_harness(m, CLIPS, n, cfg)
+        assert getattr(env, "_" + key) is val
+        g = torch.Generator().manual_seed(29)
+        torch.manual_seed(78)
+        dm.reset(torch.arange(n))
+        env._refresh_sim_tensors()
+        env._update_observations(torch.arange(n))
+        env._timestep_buf[:] = torch.randint(1, 40, (n,), generator=g, dtype=torch.int32)
+        inject_state(env, dm, m, g, noise=0.02, big_noise_rows=(6, 7, 8, 9))
+        ang = (torch.rand(16, generator=g) * 5.0 - 2.5)
+        dq = torch.stack([torch.zeros(16), torch.zeros(16), torch.sin(0.5 * ang), torch.cos(0.5 * ang)], dim=-1)
+        env._char_root_rot[16:32] = tu.quat_mul(dq, env._char_root_rot[16:32])
+        shift = torch.zeros(n, 3); shift[24:40, 0:2] = torch.rand(16, 2, generator=g) * 4.0 - 2.0
+        shift[40:56, 2] = torch.rand(16, generator=g) * 1.0 - 0.5          # lifted / lowered: what track_root_h decides about
+        env._char_root_pos[:] = env._char_root_pos + shift
+        bp, br = m.forward_kinematics(env._char_root_pos, env._char_root_rot, m.dof_to_rot(env._char_dof_pos))
+        env._char_rigid_body_pos[:] = bp
+        env._char_rigid_body_rot[:] = br
+        arrs.update(state_dict(env, dm, tag + "in_"))
+        ig_env.IGEnv._post_physics_step(env)
+        arrs.update(out_dict(env, dm, tag + "out_"))
+        print(tag, "done histogram", np.bincount(npy(env._done_buf), minlength=4), "reward range", float(env._reward_buf.min()), float(env._reward_buf.max()))
+    save("env_step_reward_done_switches", **arrs)
+
+
 def gen_env_step_root_height_obs(m):
     """`global_root_height_obs: True` (ig_parkour_env.py:84, passed to compute_char_obs as root_height_obs, :904): the root height is one
     more observation in front of the character block (ig_char_env.py:620-622) -- 1 313 columns.  With and without `global_obs`."""
@@ -778,6 +813,7 @@ if __name__ == "__main__":
     gen_env_step(model)
     gen_env_step_fall(model)
     gen_env_step_local_root(model)
+    gen_env_step_reward_done_switches(model)
     gen_env_step_global_obs(model)
     gen_env_step_root_height_obs(model)
     gen_env_step_obs_blocks(model)

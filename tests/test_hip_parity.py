@@ -223,6 +223,37 @@ def test_env_step_without_root_tracking_vs_reference_golden(tmp_path):
     assert np.abs(rew[(True, True)][16:40] - rew[(False, True)][16:40]).max() > 0.05   # the switch matters on this state
 
 
+def test_env_step_reward_and_done_switches_vs_reference_golden(tmp_path):
+    """`track_root_h: False` and `enable_early_termination: False` (off the default config), each against the reference's own
+    `_post_physics_step` (env_step_reward_done_switches.npz, see the oracle test of the same name)."""
+    from gpu_helpers import default_config, write_motion_yaml, inject, to_np, GOLDEN_WEIGHTS
+    from parc_amd.envs.hip_parkour_env import HipParkourEnv
+    g, g0 = golden("env_step_reward_done_switches"), golden("env_step")
+    for tag, key in (("h0_", "track_root_h"), ("et0_", "enable_early_termination")):
+        res = {}
+        for on in (False, True):
+            cfg = default_config()
+            cfg["env"]["dm"]["motion_file"] = write_motion_yaml(tmp_path, [str(c) for c in g0["clips"]], GOLDEN_WEIGHTS)
+            cfg["env"]["hip"]["body_pos_from_fk"] = False
+            cfg["env"][key] = on
+            env = HipParkourEnv(cfg, 64, "cuda:0", False, mirror_ref_state=False)
+            inject(env, g, tag + "in_")
+            env.step(None)
+            res[on] = (to_np(env._reward_buf).copy(), to_np(env._done_buf).copy())
+            if not on:
+                assert np.array_equal(res[on][1], g[tag + "out_done"])
+                close(res[on][0], g[tag + "out_reward"], what=tag + "reward")
+                close(env.get_fail_rates().numpy(), g[tag + "out_fail_rates"], tol=0, what="fail_rates")
+                err = np.abs(to_np(env._obs_buf) - g[tag + "out_obs"])
+                ray_bad = np.abs(to_np(env._obs_buf)[:, 871:] - g[tag + "out_obs"][:, 871:]) > TOL
+                err[:, 871:][ray_bad] = 0
+                assert ray_bad.mean() < 2e-4 and err.max() <= TOL
+        if tag == "h0_":
+            assert np.abs(res[True][0][40:56] - res[False][0][40:56]).max() > 0.02
+        else:
+            assert (res[True][1] != 0).sum() > (res[False][1] != 0).sum() + 8
+
+
 def test_env_step_with_global_observations_vs_reference_golden(tmp_path):
     """`global_obs: True` (off the default config; rejected with an error until round 3): root rotation, root velocities, root / key
     offsets of the character and of the look-ahead targets stay in the global frame (compute_char_obs ig_char_env.py:586-589, :603;

@@ -326,6 +326,36 @@ def test_env_step_without_root_tracking_vs_reference_golden(oracle, orc_char):
     assert (out[True][1] != 0).sum() > (out[False][1] != 0).sum()
 
 
+def test_env_step_reward_and_done_switches_vs_reference_golden(oracle, orc_char):
+    """`track_root_h: False` (the vertical root error leaves the root-position reward term) and `enable_early_termination: False`
+    (compute_done: only the time limit and the motion end finish an episode), each against the reference's own `_post_physics_step`
+    (env_step_reward_done_switches.npz: the turned / displaced rows of the local-root fixture + sixteen rows lifted or lowered by up to 0.5 m)."""
+    from helpers import build_oracle_scene, default_cfg, load_state_into
+    g = golden("env_step_reward_done_switches")
+    g0 = golden("env_step")
+    sc = build_oracle_scene(oracle, orc_char, g0)
+    n = g0["env_offsets"].shape[0]
+    st = sc["state"]
+    for tag, kw in (("h0_", dict(track_root_h=False)), ("et0_", dict(enable_early_termination=False))):
+        res = {}
+        for on in (False, True):
+            cfg = default_cfg(oracle, n, g0["ray_points"], g0["env_offsets"], g0["motion_offsets"], **({} if on else kw))
+            load_state_into(st, g, tag + "in_")
+            oracle.env_post_physics_step(orc_char, sc["lib"], sc["terrain"], cfg, st)
+            oracle.env_update_curriculum(sc["lib"], cfg, st)
+            res[on] = (st["reward"].copy(), st["done"].copy())
+            if not on:
+                assert np.array_equal(st["done"], g[tag + "out_done"])
+                np.testing.assert_allclose(st["reward"], g[tag + "out_reward"], atol=1e-5)
+                np.testing.assert_allclose(st["obs"], g[tag + "out_obs"], atol=1e-5)
+                np.testing.assert_array_equal(st["fail_rates"], g[tag + "out_fail_rates"])
+        # each switch matters on this state: the lifted rows' reward / the number of finished episodes
+        if tag == "h0_":
+            assert np.abs(res[True][0][40:56] - res[False][0][40:56]).max() > 0.02
+        else:
+            assert (res[True][1] != 0).sum() > (res[False][1] != 0).sum() + 8
+
+
 def test_env_step_with_global_observations_vs_reference_golden(oracle, orc_char):
     """`global_obs: True` (off the default config): compute_char_obs (ig_char_env.py:586-589, :603) and compute_tar_obs
     (mgdm_dm_util.py:417) leave root rotation, root velocities, root / key offsets in the global frame, and the targets' key offsets are not
